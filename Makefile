@@ -1,0 +1,39 @@
+# rt355 build: the gfx950 C-ABI library, the N-API shim, the CPU oracle (test infrastructure).
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+CSRC     := compute_raytracer_amd/csrc
+LIB      := compute_raytracer_amd/librt355.so
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-fast-math -Wall -Wno-unused-function
+OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels_strict.o $(CSRC)/rt_kernels_fast.o $(CSRC)/rt_assemble.o
+
+all: lib oracle node
+
+lib: $(LIB)
+
+$(CSRC)/rt_kernels_strict.o: $(CSRC)/rt_kernels_strict.hip $(CSRC)/rt_kernels.inc $(CSRC)/rt_types.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
+
+$(CSRC)/rt_kernels_fast.o: $(CSRC)/rt_kernels_fast.hip $(CSRC)/rt_kernels.inc $(CSRC)/rt_types.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=fast -c $< -o $@
+
+$(CSRC)/rt_assemble.o: $(CSRC)/rt_assemble.hip $(CSRC)/rt_types.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/rt_api.o: $(CSRC)/rt_api.hip $(CSRC)/rt_types.h include/rt355.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -s -C oracle
+
+node:
+	@if [ -f node/Makefile ]; then $(MAKE) -s -C node; fi
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -s -C oracle clean
+	@if [ -f node/Makefile ]; then $(MAKE) -s -C node clean; fi
+
+.PHONY: all lib oracle node clean

@@ -1,0 +1,393 @@
+// rt_api.hip -- host side of librt355.so: the C ABI declared in include/rt355.h.
+// One context = one GPU + one stream; see the header for what each entry point replaces in
+// the reference's renderer-raytracing.ts.  No CPU fallback: without a gfx950 device
+// rt_create fails and nothing else can be called.
+#include "../../include/rt355.h"
+#include "rt_types.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what) {
+    g_err = what;
+    return code;
+}
+int fail_hip(hipError_t e, const char* where) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+    g_err = buf;
+    return RT_ERR_HIP;
+}
+#define RT_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return fail_hip(e_, #call);              \
+    } while (0)
+
+uint32_t tiles_total(uint32_t H) { return (H + 7u) / 8u; }
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the last enqueued render
+    hipEvent_t ev_prep0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    uint32_t W = 0, H = 0;
+    uint32_t rank = 0, world = 1;
+    float params[24] = {0};
+    bool have_params = false;
+    bool scene_dirty = true;             // params or spheres changed since the last prep
+    float* d_records = nullptr;
+    uint32_t n = 0, cap_n = 0;
+    bool have_spheres = false;
+    float4 *d_geo = nullptr, *d_lgt = nullptr, *d_cam = nullptr, *d_col = nullptr;
+    uint8_t* d_face[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
+    uint8_t* d_out = nullptr;
+    size_t out_bytes = 0;
+    unsigned long long* d_rays = nullptr;
+    unsigned long long* h_rays = nullptr;  // pinned
+    int mode = RT_MODE_FAST;
+    int variant = 0;
+    int kernel = RT_KERNEL_RAYTRACER;
+    bool pending = false;                  // a render is enqueued and not yet waited for
+    bool timed = false;
+    rt_stats stats = {};
+};
+
+extern "C" {
+
+int rt_abi_version(void) { return RT355_ABI_VERSION; }
+
+const char* rt_last_error(rt_ctx*) { return g_err.c_str(); }
+
+int rt_create(int device, rt_ctx** out) {
+    if (!out) return fail(RT_ERR_INVALID_ARG, "rt_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(RT_ERR_NO_DEVICE, "rt_create: no HIP device visible (this library has no CPU path)");
+    }
+    if (device < 0 || device >= count) return fail(RT_ERR_NO_DEVICE, "rt_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        char buf[200];
+        std::snprintf(buf, sizeof buf, "rt_create: device %d is %s; librt355 carries gfx950 code only", device,
+                      prop.gcnArchName);
+        return fail(RT_ERR_NO_DEVICE, buf);
+    }
+    RT_HIP(hipSetDevice(device));
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(RT_ERR_HIP, "rt_create: out of host memory");
+    c->device = device;
+    hipError_t err;
+    if ((err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (err = hipEventCreate(&c->ev_prep0)) != hipSuccess || (err = hipEventCreate(&c->ev_k0)) != hipSuccess ||
+        (err = hipEventCreate(&c->ev_k1)) != hipSuccess ||
+        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), sizeof(unsigned long long))) != hipSuccess ||
+        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), sizeof(unsigned long long), hipHostMallocDefault)) !=
+            hipSuccess) {
+        rt_destroy(c);
+        return fail_hip(err, "rt_create: stream/event/counter setup");
+    }
+    *c->h_rays = 0;
+    c->last_stream = c->stream;
+    *out = c;
+    return RT_OK;
+}
+
+int rt_destroy(rt_ctx* c) {
+    if (!c) return RT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->last_stream && c->last_stream != c->stream && c->pending) (void)hipStreamSynchronize(c->last_stream);
+    (void)hipFree(c->d_records);
+    (void)hipFree(c->d_geo);
+    (void)hipFree(c->d_lgt);
+    (void)hipFree(c->d_cam);
+    (void)hipFree(c->d_col);
+    for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
+    (void)hipFree(c->d_out);
+    (void)hipFree(c->d_rays);
+    if (c->h_rays) (void)hipHostFree(c->h_rays);
+    if (c->ev_prep0) (void)hipEventDestroy(c->ev_prep0);
+    if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
+    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+static uint32_t local_tiles(const rt_ctx* c) { return rt_tiles_of_rank(c->H, c->rank, c->world); }
+
+uint32_t rt_tiles_of_rank(uint32_t height, uint32_t rank, uint32_t world) {
+    if (world == 0 || rank >= world) return 0;
+    const uint32_t t = tiles_total(height);
+    return t > rank ? (t - rank + world - 1u) / world : 0u;
+}
+
+uint32_t rt_padded_tiles(uint32_t height, uint32_t world) {
+    if (world == 0) return 0;
+    return (tiles_total(height) + world - 1u) / world;
+}
+
+static int ensure_out(rt_ctx* c) {
+    // sized for the padded tile count so that the buffer can be an all-gather operand
+    const size_t need = (size_t)rt_padded_tiles(c->H, c->world) * 8u * c->W * 4u;
+    if (need > c->out_bytes || !c->d_out) {
+        RT_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_out);
+        c->d_out = nullptr;
+        c->out_bytes = 0;
+        if (need) {
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_out), need));
+            RT_HIP(hipMemsetAsync(c->d_out, 0, need, c->stream));
+            c->out_bytes = need;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_resize: ctx is NULL");
+    if (width == 0 || height == 0 || width > 65536u || height > 65536u)
+        return fail(RT_ERR_INVALID_ARG, "rt_resize: width/height must be in 1..65536");
+    RT_HIP(hipSetDevice(c->device));
+    c->W = width;
+    c->H = height;
+    return ensure_out(c);
+}
+
+int rt_set_partition(rt_ctx* c, uint32_t rank, uint32_t world) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_set_partition: ctx is NULL");
+    if (world == 0 || rank >= world) return fail(RT_ERR_INVALID_ARG, "rt_set_partition: need rank < world");
+    RT_HIP(hipSetDevice(c->device));
+    c->rank = rank;
+    c->world = world;
+    if (c->W && c->H) return ensure_out(c);
+    return RT_OK;
+}
+
+int rt_write_params(rt_ctx* c, const float params[24]) {
+    if (!c || !params) return fail(RT_ERR_INVALID_ARG, "rt_write_params: NULL argument");
+    std::memcpy(c->params, params, sizeof c->params);   // travels in the kernarg segment
+    c->have_params = true;
+    c->scene_dirty = true;
+    return RT_OK;
+}
+
+int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
+    if (!c || (n && !records)) return fail(RT_ERR_INVALID_ARG, "rt_write_spheres: NULL argument");
+    if (n > (1u << 24)) return fail(RT_ERR_INVALID_ARG, "rt_write_spheres: more than 2^24 spheres");
+    RT_HIP(hipSetDevice(c->device));
+    if (n > c->cap_n) {
+        RT_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_records); (void)hipFree(c->d_geo); (void)hipFree(c->d_lgt);
+        (void)hipFree(c->d_cam); (void)hipFree(c->d_col);
+        c->d_records = nullptr; c->d_geo = c->d_lgt = c->d_cam = c->d_col = nullptr;
+        c->cap_n = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_records), (size_t)n * 32u));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_geo), (size_t)n * 16u));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_lgt), (size_t)n * 16u));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_cam), (size_t)n * 16u));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_col), (size_t)n * 16u));
+        c->cap_n = n;
+    }
+    if (n) {
+        RT_HIP(hipMemcpyAsync(c->d_records, records, (size_t)n * 32u, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(hipStreamSynchronize(c->stream));   // caller may free `records` now (writeBuffer semantics)
+    }
+    c->n = n;
+    c->have_spheres = true;
+    c->scene_dirty = true;
+    return RT_OK;
+}
+
+int rt_write_cubemap_face(rt_ctx* c, int face, uint32_t w, uint32_t h, const uint8_t* rgba) {
+    if (!c || !rgba) return fail(RT_ERR_INVALID_ARG, "rt_write_cubemap_face: NULL argument");
+    if (face < 0 || face > 5) return fail(RT_ERR_INVALID_ARG, "rt_write_cubemap_face: face must be 0..5");
+    if (w == 0 || h == 0 || w > 16384u || h > 16384u)
+        return fail(RT_ERR_INVALID_ARG, "rt_write_cubemap_face: face size must be in 1..16384");
+    RT_HIP(hipSetDevice(c->device));
+    const size_t bytes = (size_t)w * h * 4u;
+    if (c->fw[face] != w || c->fh[face] != h || !c->d_face[face]) {
+        RT_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_face[face]);
+        c->d_face[face] = nullptr;
+        c->fw[face] = c->fh[face] = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_face[face]), bytes < 16 ? 16 : bytes));
+        c->fw[face] = w;
+        c->fh[face] = h;
+    }
+    RT_HIP(hipMemcpyAsync(c->d_face[face], rgba, bytes, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+#define RT_UNSUPPORTED(name)                                                                      \
+    return fail(RT_ERR_UNSUPPORTED, name ": the triangle/BVH path (SURVEY.md 8(f) row 1) is not built yet")
+
+int rt_write_triangles(rt_ctx*, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_triangles"); }
+int rt_write_nodes(rt_ctx*, size_t, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_nodes"); }
+int rt_write_blas(rt_ctx*, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_blas"); }
+int rt_write_tri_lookup(rt_ctx*, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_tri_lookup"); }
+int rt_write_blas_lookup(rt_ctx*, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_blas_lookup"); }
+int rt_write_mesh_texture(rt_ctx*, uint32_t, uint32_t, const uint8_t*) { RT_UNSUPPORTED("rt_write_mesh_texture"); }
+
+int rt_select_kernel(rt_ctx* c, int kernel) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_select_kernel: ctx is NULL");
+    if (kernel == RT_KERNEL_RAYTRACER) { c->kernel = kernel; return RT_OK; }
+    if (kernel == RT_KERNEL_HEATMAP)
+        return fail(RT_ERR_UNSUPPORTED, "rt_select_kernel: the heatmap kernel (SURVEY.md 8(f) row 4) is not built yet");
+    return fail(RT_ERR_INVALID_ARG, "rt_select_kernel: unknown kernel");
+}
+
+int rt_set_mode(rt_ctx* c, int mode) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_set_mode: ctx is NULL");
+    if (mode != RT_MODE_FAST && mode != RT_MODE_STRICT) return fail(RT_ERR_INVALID_ARG, "rt_set_mode: unknown mode");
+    c->mode = mode;
+    return RT_OK;
+}
+
+int rt_set_variant(rt_ctx* c, int variant) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_set_variant: ctx is NULL");
+    if (variant < 0 || variant > 4) return fail(RT_ERR_INVALID_ARG, "rt_set_variant: unknown variant");
+    c->variant = variant;
+    return RT_OK;
+}
+
+static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
+    if (!c->W || !c->H) return fail(RT_ERR_STATE, "rt_render: rt_resize has not been called");
+    if (!c->have_params) return fail(RT_ERR_STATE, "rt_render: rt_write_params has not been called");
+    if (!c->have_spheres) return fail(RT_ERR_STATE, "rt_render: rt_write_spheres has not been called");
+    for (int i = 0; i < 6; ++i)
+        if (!c->d_face[i]) return fail(RT_ERR_STATE, "rt_render: all six cube map faces must be written first");
+    if (c->pending) return fail(RT_ERR_STATE, "rt_render: previous frame not waited for (one frame in flight, RR:467)");
+    RT_HIP(hipSetDevice(c->device));
+
+    RT_HIP(hipEventRecord(c->ev_prep0, s));
+    if (s != c->stream) c->scene_dirty = true;   // no ordering between streams is assumed
+    if (c->scene_dirty && c->n) {
+        RtPrepArgs pa;
+        std::memcpy(pa.p, c->params, sizeof pa.p);
+        pa.N = c->n;
+        pa.records = c->d_records;
+        pa.geo = c->d_geo; pa.lgt = c->d_lgt; pa.cam = c->d_cam; pa.col = c->d_col;
+        RT_HIP(rt_launch_prep_strict(pa, s));
+    }
+    c->scene_dirty = (s != c->stream);
+    RT_HIP(hipMemsetAsync(c->d_rays, 0, sizeof(unsigned long long), s));
+
+    RtFrameArgs fa;
+    std::memcpy(fa.p, c->params, sizeof fa.p);
+    fa.W = c->W; fa.H = c->H; fa.N = c->n;
+    fa.tile_first = c->rank; fa.tile_step = c->world; fa.n_local_tiles = local_tiles(c);
+    fa.geo = c->d_geo; fa.lgt = c->d_lgt; fa.cam = c->d_cam; fa.col = c->d_col;
+    for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
+    fa.out = dst;
+    fa.rays = c->d_rays;
+    RtLaunchCfg cfg;
+    cfg.variant = c->variant;
+
+    RT_HIP(hipEventRecord(c->ev_k0, s));
+    if (c->mode == RT_MODE_STRICT) RT_HIP(rt_launch_trace_strict(fa, cfg, s));
+    else                           RT_HIP(rt_launch_trace_fast(fa, cfg, s));
+    RT_HIP(hipEventRecord(c->ev_k1, s));
+    RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    c->last_stream = s;
+    c->pending = true;
+    c->timed = true;
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* c) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_render: ctx is NULL");
+    return enqueue(c, c->d_out, c->stream);
+}
+
+int rt_render_to(rt_ctx* c, void* device_dst, size_t cap, void* hip_stream) {
+    if (!c || !device_dst) return fail(RT_ERR_INVALID_ARG, "rt_render_to: NULL argument");
+    const size_t need = (size_t)local_tiles(c) * 8u * c->W * 4u;
+    if (cap < need) return fail(RT_ERR_CAPACITY, "rt_render_to: destination smaller than local_tiles*8*W*4");
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return enqueue(c, static_cast<uint8_t*>(device_dst), s);
+}
+
+int rt_wait(rt_ctx* c) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_wait: ctx is NULL");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->last_stream));
+    if (c->pending) {
+        c->pending = false;
+        c->stats.frames += 1;
+        c->stats.rays = *c->h_rays;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev_k0, c->ev_k1) == hipSuccess) c->stats.kernel_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev_prep0, c->ev_k0) == hipSuccess) c->stats.prep_ms = ms;
+        (void)hipGetLastError();
+    }
+    return RT_OK;
+}
+
+int rt_read_pixels(rt_ctx* c, uint8_t* dst, size_t cap) {
+    if (!c || !dst) return fail(RT_ERR_INVALID_ARG, "rt_read_pixels: NULL argument");
+    if (!c->d_out) return fail(RT_ERR_STATE, "rt_read_pixels: no colour buffer (rt_resize first)");
+    int rc = rt_wait(c);
+    if (rc != RT_OK) return rc;
+    // rows owned by this rank, clipped to the frame (the last tile may be partial)
+    const uint32_t lt = local_tiles(c);
+    size_t rows = 0;
+    for (uint32_t j = 0; j < lt; ++j) {
+        const uint32_t y0 = (c->rank + j * c->world) * 8u;
+        rows += (c->H - y0 >= 8u) ? 8u : (c->H - y0);
+    }
+    // the compact buffer keeps 8 rows per tile; only the final tile can be short, so the
+    // first `rows` rows are contiguous valid data
+    const size_t need = rows * c->W * 4u;
+    if (cap < need) return fail(RT_ERR_CAPACITY, "rt_read_pixels: destination smaller than the local rows * W * 4");
+    RT_HIP(hipMemcpyAsync(dst, c->d_out, need, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx* c, rt_stats* out) {
+    if (!c || !out) return fail(RT_ERR_INVALID_ARG, "rt_get_stats: NULL argument");
+    c->stats.width = c->W;
+    c->stats.height = c->H;
+    c->stats.local_tiles = local_tiles(c);
+    c->stats.spheres = c->n;
+    c->stats.mode = c->mode;
+    *out = c->stats;
+    return RT_OK;
+}
+
+int rt_assemble_frame(rt_ctx* c, const void* gathered, void* frame, uint32_t world, void* hip_stream) {
+    if (!c || !gathered || !frame) return fail(RT_ERR_INVALID_ARG, "rt_assemble_frame: NULL argument");
+    if (world == 0) return fail(RT_ERR_INVALID_ARG, "rt_assemble_frame: world must be >= 1");
+    if (!c->W || !c->H) return fail(RT_ERR_STATE, "rt_assemble_frame: rt_resize has not been called");
+    RT_HIP(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    RT_HIP(rt_launch_assemble(static_cast<const uint8_t*>(gathered), static_cast<uint8_t*>(frame), c->W, c->H, world,
+                              rt_padded_tiles(c->H, world), s));
+    return RT_OK;
+}
+
+int rt_device_pixels(rt_ctx* c, void** out_ptr, size_t* out_bytes) {
+    if (!c || !out_ptr || !out_bytes) return fail(RT_ERR_INVALID_ARG, "rt_device_pixels: NULL argument");
+    if (!c->d_out) return fail(RT_ERR_STATE, "rt_device_pixels: no colour buffer (rt_resize first)");
+    *out_ptr = c->d_out;
+    *out_bytes = c->out_bytes;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+/*
+ * rt355.h -- C ABI of librt355.so, the MI355X (gfx950) stand-in for the WebGPU
+ * calls the reference's RendererRaytracing makes.
+ *
+ * Every entry point names the reference interface it replaces; citations are
+ * relative to the reference repository:
+ *   RR = src/rendering-raycast/renderer-raytracing.ts
+ *   RK = src/rendering-raycast/shaders/raytracer-kernel.wgsl
+ *   CM = src/material/cubemap-material.ts
+ *   MT = src/material/material.ts
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; no C++/torch/HIP types in any signature
+ *     (a HIP stream crosses as void*).
+ *   - every function returns int: RT_OK (0) or a negative rt_status.  The message
+ *     for the most recent failure on the calling thread is rt_last_error().
+ *   - every rt_write_* copies out of caller memory before it returns, as
+ *     GPUQueue.writeBuffer does (RR:165); the caller may reuse/free at once.
+ *   - byte layouts are exactly the ones RR writes (f32 indices and counts,
+ *     vec3 padded to 16 B), so buffers captured from a browser run replay unchanged.
+ *   - a context is bound to ONE device and is not thread-safe (single JS thread in
+ *     the reference).  Multi-GPU = one process and one context per GPU; the frame
+ *     is split into 8-row tiles (one WGSL workgroup row, RK:73), tile t is rendered
+ *     by rank t % world, and the host gathers the compact per-rank tile buffers
+ *     with RCCL (see rt_set_partition, rt_render_to, rt_assemble_frame).
+ *   - there is no CPU fallback anywhere in this library.
+ */
+#ifndef RT355_H
+#define RT355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT355_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,  /* null pointer, bad size, bad enum                      */
+    RT_ERR_NO_DEVICE = -2,    /* no gfx950 device / ordinal out of range                */
+    RT_ERR_HIP = -3,          /* a HIP runtime call failed (message has the hipError)   */
+    RT_ERR_UNSUPPORTED = -4,  /* entry point declared for the boundary, not built yet   */
+    RT_ERR_STATE = -5,        /* call order: e.g. render before resize / write_params   */
+    RT_ERR_CAPACITY = -6      /* destination buffer too small                           */
+} rt_status;
+
+typedef enum rt_kernel {
+    RT_KERNEL_RAYTRACER = 0,  /* RR:70-72 showRaytracer()  */
+    RT_KERNEL_HEATMAP = 1     /* RR:74-76 showHeatmap()    (unsupported) */
+} rt_kernel;
+
+/* Arithmetic mode of the ray-trace kernel.
+ * RT_MODE_STRICT: no FMA contraction, IEEE div/sqrt, the oracle's operation order ->
+ *                 expected bit-identical to oracle/rt_oracle.c.
+ * RT_MODE_FAST  : FMA contraction allowed (default); parity within the tolerance stated
+ *                 in tests/test_parity_gpu.py. */
+typedef enum rt_mode { RT_MODE_FAST = 0, RT_MODE_STRICT = 1 } rt_mode;
+
+typedef struct rt_ctx rt_ctx;
+
+typedef struct rt_stats {
+    uint32_t width, height;       /* current target                                        */
+    uint32_t local_tiles;         /* 8-row tiles this context renders                      */
+    uint32_t spheres;             /* primitives in the scene                               */
+    uint64_t rays;                /* scene traversals of the last completed render:
+                                     primary/reflection (RK:114) + shadow (RK:153) rays    */
+    float kernel_ms;              /* hipEvent time of the last ray-trace kernel launch     */
+    float prep_ms;                /* hipEvent time of the per-frame scene preparation      */
+    uint32_t frames;              /* completed renders since rt_create                     */
+    int mode;                     /* rt_mode in effect                                     */
+} rt_stats;
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+
+/* Replaces navigator.gpu.requestAdapter()/requestDevice() (RR:82-86).  `device` is the HIP
+ * ordinal; one stream is created on it.  Fails (RT_ERR_NO_DEVICE) when no GPU is present. */
+int rt_create(int device, rt_ctx** out);
+int rt_destroy(rt_ctx* ctx);
+
+/* Thread-local message of the last failure ("" if none).  `ctx` may be NULL. */
+const char* rt_last_error(rt_ctx* ctx);
+
+int rt_abi_version(void);
+
+/* ---- resources ----------------------------------------------------------------------- */
+
+/* Replaces createTexture({size:{width,height}, format:'rgba8unorm'}) (RR:102-109): the
+ * W x H x 4 B colour buffer, row-major, row 0 = top.  Re-callable. */
+int rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height);
+
+/* Replaces queue.writeBuffer(sceneParameters, 0, Float32Array(24)) (RR:157-165).
+ * p[0..2] cameraPos, [4..6] forwards, [8..10] right, [12..14] up, [16..18] lightPosition,
+ * [19] lightIntensity, [20] minIntensity, [21] maxBounces (f32, truncated by u32(), RK:110). */
+int rt_write_params(rt_ctx* ctx, const float params[24]);
+
+/* Sphere primitives: `n` records of 8 f32 {cx,cy,cz,_, r,g,b, radius} = the WGSL layout of
+ * the reference's commented `struct Sphere` (RK:13-17; model/sphere.ts:1-10).  Takes the
+ * place of the triangle/BVH uploads (RR:198-229) for sphere scenes.  n may be 0. */
+int rt_write_spheres(rt_ctx* ctx, const float* records, uint32_t n);
+
+/* Replaces copyExternalImageToTexture(face i) (CM:73-77).  face order as CM:40-47:
+ * 0 +X, 1 -X, 2 +Y, 3 -Y, 4 +Z, 5 -Z; rgba8unorm, w*h*4 bytes, row 0 = top. */
+int rt_write_cubemap_face(rt_ctx* ctx, int face, uint32_t w, uint32_t h, const uint8_t* rgba);
+
+/* Triangle / BVH path of the reference.  Declared so that the boundary
+ * is complete; return RT_ERR_UNSUPPORTED until that row is built. */
+int rt_write_triangles(rt_ctx* ctx, const float* data, uint32_t n_triangles);        /* RR:198-209 */
+int rt_write_nodes(rt_ctx* ctx, size_t byte_offset, const float* data, uint32_t n);  /* RR:184-192, 212-223 */
+int rt_write_blas(rt_ctx* ctx, const float* data, uint32_t n_blas);                  /* RR:169-174 */
+int rt_write_tri_lookup(rt_ctx* ctx, const float* data, uint32_t n);                 /* RR:225-229 */
+int rt_write_blas_lookup(rt_ctx* ctx, const float* data, uint32_t n);                /* RR:177-181 */
+int rt_write_mesh_texture(rt_ctx* ctx, uint32_t w, uint32_t h, const uint8_t* rgba); /* MT:61-65 */
+
+/* Replaces selecting one of the two compute pipelines (RR:70-76, RR:356-374). */
+int rt_select_kernel(rt_ctx* ctx, int kernel);
+
+/* Arithmetic mode (no reference counterpart: WGSL leaves fp contraction to the driver). */
+int rt_set_mode(rt_ctx* ctx, int mode);
+
+/* Kernel variant for A/B measurements (0 = library default).  See DESIGN.md. */
+int rt_set_variant(rt_ctx* ctx, int variant);
+
+/* ---- multi-GPU partition --------------------------------------------------------------- */
+
+/* This context renders the 8-row tiles t with t % world == rank, into a compact buffer of
+ * rt_local_tiles() * 8 rows.  Default rank 0, world 1 = the whole frame. */
+int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t world);
+
+/* Tiles owned by `rank`, and the padded per-rank tile count (max over ranks) that sizes the
+ * all-gather message: bytes = rt_padded_tiles * 8 * width * 4. */
+uint32_t rt_tiles_of_rank(uint32_t height, uint32_t rank, uint32_t world);
+uint32_t rt_padded_tiles(uint32_t height, uint32_t world);
+
+/* ---- frame ------------------------------------------------------------------------------- */
+
+/* Replaces beginComputePass/setPipeline/setBindGroup/dispatchWorkgroups(ceil(W/8),
+ * ceil(H/8),1)/submit (RR:442-446, RR:465): enqueues scene preparation + the ray-trace
+ * kernel on the context's stream and returns without waiting. */
+int rt_render(rt_ctx* ctx);
+
+/* Replaces `await queue.onSubmittedWorkDone()` (RR:467). */
+int rt_wait(rt_ctx* ctx);
+
+/* Copies this context's tiles (world 1: the W*H*4 frame) to host memory.
+ * Needs cap >= local_tiles*8*W*4 clipped to the frame. */
+int rt_read_pixels(rt_ctx* ctx, uint8_t* dst, size_t cap);
+
+int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+
+/* ---- device-pointer interop (process-per-GPU hosts: torch.distributed / RCCL) --------- */
+
+/* As rt_render, but the kernel runs on `hip_stream` (a hipStream_t; NULL = the context's
+ * stream) and writes the compact tile buffer to `device_dst` (device memory of this
+ * context's GPU, >= rt_padded_tiles*8*W*4 bytes).  Nothing is copied to the host. */
+int rt_render_to(rt_ctx* ctx, void* device_dst, size_t cap, void* hip_stream);
+
+/* De-interleaves an all-gathered buffer [world][padded_tiles][8][W][4] into the row-major
+ * frame [H][W][4] (both device memory) on `hip_stream`. */
+int rt_assemble_frame(rt_ctx* ctx, const void* gathered, void* frame, uint32_t world,
+                      void* hip_stream);
+
+/* Device address of the context's own colour buffer (valid until rt_resize/rt_destroy). */
+int rt_device_pixels(rt_ctx* ctx, void** out_ptr, size_t* out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT355_H */

@@ -1,0 +1,93 @@
+/*
+ * rt_oracle.h -- CPU restatement of the reference ray-trace compute shader.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the C-ABI library
+ * librt355.so, the Python/Node host layers) may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and there only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (GmxMahdi/compute-raytracer) ships no tests,
+ * golden images or known-answer vectors, and its WGSL cannot be executed in
+ * the build container (no WebGPU implementation).  This oracle follows the
+ * WGSL line by line (citations below, relative to /root/reference/) and is
+ * cross-checked against an independent numpy restatement (oracle/rt_oracle_np.py),
+ * but no artefact of the reference itself pins it.
+ *
+ * Reference files followed:
+ *   RK = src/rendering-raycast/shaders/raytracer-kernel.wgsl
+ *   HK = src/rendering-raycast/shaders/heatmap-kernel.wgsl
+ *   RR = src/rendering-raycast/renderer-raytracing.ts
+ *
+ * Arithmetic conventions (where WGSL leaves precision to the implementation the
+ * oracle takes the correctly-rounded IEEE-754 binary32 reading, no FMA
+ * contraction, left-to-right evaluation as the WGSL grammar parses it):
+ *   dot(a,b)      = (a.x*b.x + a.y*b.y) + a.z*b.z
+ *   length(v)     = sqrtf(dot(v,v))
+ *   normalize(v)  = v / length(v)            (componentwise IEEE division)
+ *   reflect(e1,n) = e1 - (2*dot(n,e1))*n     (WGSL spec definition)
+ *   clamp(x,lo,hi)= min(max(x,lo),hi)
+ *   rgba8unorm store = floor(clamp(c,0,1)*255 + 0.5), NaN -> 0
+ *   cube sample   = Vulkan/WebGPU major-axis face selection, bilinear inside the
+ *                   face with clamp-to-edge, lerp written a + (b-a)*f so that a
+ *                   constant face returns its colour exactly; texel = byte/255.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    uint32_t w, h;
+    const uint8_t* rgba; /* w*h*4 bytes, row-major, row 0 = top */
+} rt_oracle_face;
+
+typedef struct {
+    float t;
+    float normal[3];
+    int hit;
+} rt_oracle_hit;
+
+/* HK:307-331 (commented-out hitSphere).  sphere = 8 floats {cx,cy,cz,_,r,g,b,radius}
+ * (layout of the commented struct Sphere, RK:13-17). */
+rt_oracle_hit rt_oracle_hit_sphere(const float origin[3], const float dir[3],
+                                   const float sphere[8], float t_min, float t_max);
+
+/* RK:78-86 ray generation for pixel (x,y) of a W x H target. */
+void rt_oracle_ray_dir(const float params[24], uint32_t W, uint32_t H, uint32_t x, uint32_t y,
+                       float dir[3]);
+
+/* textureSampleLevel(skyTex, texSamp, dir, 0).rgb  (RK:92, RK:123) */
+void rt_oracle_cube_sample(const rt_oracle_face faces[6], const float dir[3], float rgb[3]);
+
+/* rgba8unorm quantisation of one channel (RK:58, RK:98). */
+uint8_t rt_oracle_unorm8(float c);
+
+/* RK:101-144 rayColor: returns rgb + dist, adds the number of scene traversals
+ * (primary/reflection rays RK:114 + shadow rays RK:153) to *rays. */
+void rt_oracle_ray_color(const float params[24], const float* spheres, uint32_t n,
+                         const rt_oracle_face faces[6], const float origin[3], const float dir[3],
+                         float rgbd[4], uint64_t* rays);
+
+/* RK:73-99 for every pixel of the 8-row tiles t = tile_first, tile_first+tile_step, ...
+ * (tile t covers rows 8t .. 8t+7).  tile_first=0, tile_step=1 renders the full frame.
+ * out_rgba8 : full W*H*4 frame, only the selected rows are written (may be NULL)
+ * out_rgb   : full W*H*3 float frame of the pre-quantisation pixelColor (may be NULL)
+ * rays_out  : total scene traversals over the rendered pixels (may be NULL)
+ * threads   : OpenMP threads (<=0: all)
+ */
+int rt_oracle_render(const float params[24], const float* spheres, uint32_t n,
+                     const rt_oracle_face faces[6], uint32_t W, uint32_t H,
+                     uint32_t tile_first, uint32_t tile_step,
+                     uint8_t* out_rgba8, float* out_rgb, uint64_t* rays_out, int threads);
+
+int rt_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+"""ctypes wrapper around oracle/librt_oracle.so.  TEST INFRASTRUCTURE ONLY (see rt_oracle.h):
+importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from
+the product package.  PARITY UNPINNED (no reference fixtures exist)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class _Face(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_uint32), ("h", ctypes.c_uint32), ("rgba", ctypes.c_void_p)]
+
+
+class _Hit(ctypes.Structure):
+    _fields_ = [("t", ctypes.c_float), ("normal", ctypes.c_float * 3), ("hit", ctypes.c_int)]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "librt_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        fp = ctypes.POINTER(ctypes.c_float)
+        L.rt_oracle_render.restype = ctypes.c_int
+        L.rt_oracle_render.argtypes = [fp, fp, ctypes.c_uint32, ctypes.POINTER(_Face), ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+        L.rt_oracle_hit_sphere.restype = _Hit
+        L.rt_oracle_hit_sphere.argtypes = [fp, fp, fp, ctypes.c_float, ctypes.c_float]
+        L.rt_oracle_ray_dir.restype = None
+        L.rt_oracle_ray_dir.argtypes = [fp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, fp]
+        L.rt_oracle_cube_sample.restype = None
+        L.rt_oracle_cube_sample.argtypes = [ctypes.POINTER(_Face), fp, fp]
+        L.rt_oracle_unorm8.restype = ctypes.c_uint8
+        L.rt_oracle_unorm8.argtypes = [ctypes.c_float]
+        L.rt_oracle_ray_color.restype = None
+        L.rt_oracle_ray_color.argtypes = [fp, fp, ctypes.c_uint32, ctypes.POINTER(_Face), fp, fp, fp,
+                                          ctypes.POINTER(ctypes.c_uint64)]
+        L.rt_oracle_max_threads.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _faces(faces):
+    keep = [np.ascontiguousarray(f, dtype=np.uint8) for f in faces]
+    arr = (_Face * 6)()
+    for i, f in enumerate(keep):
+        arr[i].w, arr[i].h, arr[i].rgba = f.shape[1], f.shape[0], f.ctypes.data
+    return arr, keep
+
+
+def render(params, spheres, faces, W, H, tile_first=0, tile_step=1, want_float=False, threads=0):
+    """Returns (rgba8 (H,W,4) uint8, rgb (H,W,3) float32 or None, rays)."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 8)
+    arr, keep = _faces(faces)
+    out = np.zeros((H, W, 4), dtype=np.uint8)
+    outf = np.zeros((H, W, 3), dtype=np.float32) if want_float else None
+    rays = ctypes.c_uint64(0)
+    rc = lib().rt_oracle_render(_fp(params), _fp(spheres), spheres.shape[0], arr, W, H, tile_first, tile_step,
+                                out.ctypes.data, outf.ctypes.data if want_float else None,
+                                ctypes.byref(rays), threads)
+    if rc != 0:
+        raise RuntimeError("rt_oracle_render failed: %d" % rc)
+    return out, outf, rays.value
+
+
+def hit_sphere(origin, direction, sphere, t_min, t_max):
+    o = np.ascontiguousarray(origin, dtype=np.float32)
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    s = np.ascontiguousarray(sphere, dtype=np.float32)
+    h = lib().rt_oracle_hit_sphere(_fp(o), _fp(d), _fp(s), np.float32(t_min), np.float32(t_max))
+    return bool(h.hit), np.float32(h.t), np.array(list(h.normal), dtype=np.float32)
+
+
+def ray_dir(params, W, H, x, y):
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    d = np.zeros(3, np.float32)
+    lib().rt_oracle_ray_dir(_fp(params), W, H, x, y, _fp(d))
+    return d
+
+
+def cube_sample(faces, direction):
+    arr, keep = _faces(faces)
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    out = np.zeros(3, np.float32)
+    lib().rt_oracle_cube_sample(arr, _fp(d), _fp(out))
+    return out
+
+
+def unorm8(c):
+    return int(lib().rt_oracle_unorm8(np.float32(c)))
+
+
+def ray_color(params, spheres, faces, origin, direction):
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 8)
+    arr, keep = _faces(faces)
+    o = np.ascontiguousarray(origin, dtype=np.float32)
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    out = np.zeros(4, np.float32)
+    rays = ctypes.c_uint64(0)
+    lib().rt_oracle_ray_color(_fp(params), _fp(spheres), spheres.shape[0], arr, _fp(o), _fp(d), _fp(out),
+                              ctypes.byref(rays))
+    return out, rays.value
+
+
+def max_threads():
+    return lib().rt_oracle_max_threads()

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure; oracle/rt_oracle.h)."""
+    from oracle import rt_oracle_py
+    rt_oracle_py.lib()
+    return rt_oracle_py
+
+
+@pytest.fixture(scope="session")
+def constant_sky():
+    import compute_raytracer_amd as rt
+    from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
+    return rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)

@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import numpy as np
+
+import compute_raytracer_amd as rt
+from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
+
+
+def config_inputs(name, width=None, height=None, spheres=None, bounces=None):
+    cfg = dict(rt.BASELINE_CONFIGS[name])
+    if width: cfg["width"] = width
+    if height: cfg["height"] = height
+    if spheres: cfg["spheres"] = spheres
+    if bounces is not None: cfg["bounces"] = bounces
+    scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
+    return cfg, scene
+
+
+def gpu_render(scene, width, height, bounces, strict, skybox=None, variant=0, rank=0, world=1):
+    r = rt.RendererRaytracing(width, height, scene, maxBounces=bounces, rank=rank, world=world)
+    r.initialize(skybox)
+    r.set_mode(strict)
+    r.set_variant(variant)
+    r.render()
+    img = r.read_pixels()
+    st = r.stats()
+    r.close()
+    return img, st
+
+
+def oracle_render(oracle, scene, width, height, bounces, skybox=None, want_float=False, **kw):
+    sky = skybox if skybox is not None else rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    return oracle.render(scene.pack_params(bounces), scene.pack_spheres(), sky.faces, width, height,
+                         want_float=want_float, **kw)
+
+
+def diff_stats(a, b):
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))[..., :3].max(axis=-1)
+    n = d.size
+    return {
+        "pixels": n,
+        "exact": float((d == 0).sum()) / n,
+        "within1": float((d <= 1).sum()) / n,
+        "within2": float((d <= 2).sum()) / n,
+        "max": int(d.max()),
+        "n_gt1": int((d > 1).sum()),
+    }
