@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement: Mrays/s (and frames/s) of the ray-trace hot path on
+BASELINE.json's configuration C3 (3840x2160, 1024 spheres, 8 bounces), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: per-frame scene preparation + the ray-trace kernel over this rank's row
+tiles (+ for N > 1 the RCCL all-gather of the tiles and the de-interleave into the full frame
+on every rank).  Scene, cube map and parameters are resident in HBM before the timed region.
+"ray" = one scene traversal (primary/reflection RK:114 + shadow RK:153); the per-frame count is
+the kernel's own exact counter (tests check it against the oracle).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the ray-trace kernel)
+against the FP32 vector peak, which is the roof that binds this path; the HBM
+fraction the north_star asks for is reported inside it as `hbm`.  `cpu_baseline` times the CPU
+oracle (the repository's own scalar restatement of the shader: kind "port") on a bounded sample
+of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_TEST = 25          # WGSL-literal count of HK:308-311
+PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)"
+PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, help="BASELINE config (default C3; C4 when --gpus > 1)")
+    ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, scene, sky, target_s):
+    """Times the CPU oracle on every `step`-th 8-row tile of the same frame (bounded sample)."""
+    from oracle import rt_oracle_py as orc
+    W, H, B = cfg["width"], cfg["height"], cfg["bounces"]
+    p, s = scene.pack_params(B), scene.pack_spheres()
+    threads = orc.max_threads()
+    ntiles = (H + 7) // 8
+    # calibrate on a thin sample, then size the timed sample for ~target_s seconds
+    step0 = max(1, ntiles // 4)
+    t0 = time.perf_counter()
+    _, _, rays0 = orc.render(p, s, sky.faces, W, H, tile_first=step0 // 2, tile_step=step0)
+    dt0 = time.perf_counter() - t0
+    n0 = len(range(step0 // 2, ntiles, step0))
+    per_tile = dt0 / max(n0, 1)
+    want = max(1, min(ntiles, int(target_s / max(per_tile, 1e-9))))
+    step = max(1, ntiles // want)
+    t0 = time.perf_counter()
+    _, _, rays = orc.render(p, s, sky.faces, W, H, tile_first=step // 2, tile_step=step)
+    dt = time.perf_counter() - t0
+    n = len(range(step // 2, ntiles, step))
+    return {
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": "oracle/rt_oracle.c (scalar fp32 C, OpenMP over rows) on %d of %d 8-row tiles (every %d-th, "
+                  "from tile %d) of the same %dx%d/%d-sphere/%d-bounce frame: %d rays in %.1f s"
+                  % (n, ntiles, step, step // 2, W, H, cfg["spheres"], B, rays, dt),
+        "fps_equiv": (n / ntiles) / dt,
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+
+    import torch  # device memory, streams and torch.distributed only
+    import compute_raytracer_amd as rt
+    from compute_raytracer_amd import tiles
+    from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    name = a.config or ("C3" if world == 1 else "C4")
+    cfg = rt.BASELINE_CONFIGS[name]
+    W, H, N, B = cfg["width"], cfg["height"], cfg["spheres"], cfg["bounces"]
+    scene = rt.synthetic_scene(N, cfg["seed"])
+    if cfg["skybox"]:
+        sky = rt.CubemapMaterial.from_png(os.path.join(ROOT, "assets", "daylight-skybox.png"))
+    else:
+        sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+
+    r = rt.RendererRaytracing(W, H, scene, device=local_rank, maxBounces=B, rank=rank, world=world)
+    r.initialize(sky)
+    r.set_mode(a.mode == "strict")
+    r.set_variant(a.variant)
+    r.recalculateScene()   # uploads: scene resident in HBM before anything is timed
+
+    stream = torch.cuda.current_stream()
+    if world > 1:
+        msg = tiles.message_bytes(W, H, world)
+        local = torch.zeros(msg, dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(world * msg, dtype=torch.uint8, device="cuda")
+        frame = torch.empty(H * W * 4, dtype=torch.uint8, device="cuda")
+
+    def step():
+        if world == 1:
+            r.enqueue()                       # prep + ray-trace kernel on the context's stream
+        else:
+            sp = stream.cuda_stream
+            r.render_to(local.data_ptr(), local.numel(), sp)          # this rank's tiles
+            dist.all_gather_into_tensor(gathered, local)              # RCCL over xGMI
+            r.assemble_frame(gathered.data_ptr(), frame.data_ptr(), world, sp)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    r.wait()
+    kernel_ms_sum, kernel_frames = 0.0, 0
+    t0 = time.perf_counter()
+    done = 0
+    while done < a.steps:
+        chunk = min(a.steps - done, 16)       # stay inside the library's event ring
+        for _ in range(chunk):
+            step()
+        done += chunk
+        if done < a.steps:
+            r.wait()
+            st = r.stats()
+            kernel_ms_sum += st["batch_kernel_ms"]
+            kernel_frames += st["batch_frames"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    r.wait()
+    st = r.stats()
+    kernel_ms_sum += st["batch_kernel_ms"]
+    kernel_frames += st["batch_frames"]
+    rays_local = st["rays"]
+
+    if world > 1:
+        t = torch.tensor([elapsed, float(rays_local), kernel_ms_sum / max(kernel_frames, 1)],
+                         dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays_frame = int(round(float(tsum[1])))
+        kernel_ms = float(tmax[2])            # slowest rank's average kernel time
+        rays_kernel = rays_frame / world      # average rays per launch
+    else:
+        rays_frame = rays_local
+        kernel_ms = kernel_ms_sum / max(kernel_frames, 1)
+        rays_kernel = rays_frame
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = rays_frame * a.steps / elapsed / 1e6
+        flops_launch = FLOP_PER_TEST * N * rays_kernel
+        achieved_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
+        local_rows = tiles.tiles_of_rank(H, 0, world) * 8
+        hbm_bytes = 4 * W * min(local_rows, H) + 32 * N + 96
+        hbm_gbps = hbm_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                key = "%s/%s/v%d/n%d" % (name, a.mode, a.variant, world)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s at %dx%d, %d spheres, %d bounces" % (W, H, N, B),
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "frames_per_s": 1e3 / ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d, %d spheres (seed %d), %d bounces, constant sky, reference default "
+                                   "camera/light" % (name, W, H, N, cfg["seed"], B),
+                       "mode": a.mode, "variant": a.variant, "rays_per_frame": rays_frame,
+                       "parallelism": "row-tiles x%d%s" % (world, "" if world == 1 else " + RCCL all-gather")},
+            "roofline": {
+                "bound": "valu-fp32", "kernel": "trace_pixels",
+                "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / PEAK_FP32_TFLOPS,
+                "traffic": traffic,
+                "kernel_ms_avg": kernel_ms, "flop_per_launch": flops_launch,
+                "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": hbm_gbps / PEAK_HBM_GBPS, "bytes_per_launch": hbm_bytes},
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, scene, sky, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

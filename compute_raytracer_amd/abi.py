@@ -35,6 +35,7 @@ class RtStats(ctypes.Structure):
         ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("local_tiles", ctypes.c_uint32),
         ("spheres", ctypes.c_uint32), ("rays", ctypes.c_uint64), ("kernel_ms", ctypes.c_float),
         ("prep_ms", ctypes.c_float), ("frames", ctypes.c_uint32), ("mode", ctypes.c_int),
+        ("batch_frames", ctypes.c_uint32), ("batch_kernel_ms", ctypes.c_float),
     ]
 
 

@@ -38,7 +38,9 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the last enqueued render
-    hipEvent_t ev_prep0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    hipEvent_t ev_prep0[RT355_MAX_IN_FLIGHT] = {nullptr}, ev_k0[RT355_MAX_IN_FLIGHT] = {nullptr},
+               ev_k1[RT355_MAX_IN_FLIGHT] = {nullptr};
+    uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
     uint32_t W = 0, H = 0;
     uint32_t rank = 0, world = 1;
     float params[24] = {0};
@@ -57,8 +59,6 @@ struct rt_ctx {
     int mode = RT_MODE_FAST;
     int variant = 0;
     int kernel = RT_KERNEL_RAYTRACER;
-    bool pending = false;                  // a render is enqueued and not yet waited for
-    bool timed = false;
     rt_stats stats = {};
 };
 
@@ -91,9 +91,13 @@ int rt_create(int device, rt_ctx** out) {
     if (!c) return fail(RT_ERR_HIP, "rt_create: out of host memory");
     c->device = device;
     hipError_t err;
-    if ((err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (err = hipEventCreate(&c->ev_prep0)) != hipSuccess || (err = hipEventCreate(&c->ev_k0)) != hipSuccess ||
-        (err = hipEventCreate(&c->ev_k1)) != hipSuccess ||
+    err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < RT355_MAX_IN_FLIGHT && err == hipSuccess; ++i) {
+        if ((err = hipEventCreate(&c->ev_prep0[i])) != hipSuccess) break;
+        if ((err = hipEventCreate(&c->ev_k0[i])) != hipSuccess) break;
+        err = hipEventCreate(&c->ev_k1[i]);
+    }
+    if (err != hipSuccess ||
         (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), sizeof(unsigned long long))) != hipSuccess ||
         (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), sizeof(unsigned long long), hipHostMallocDefault)) !=
             hipSuccess) {
@@ -110,7 +114,7 @@ int rt_destroy(rt_ctx* c) {
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->last_stream && c->last_stream != c->stream && c->pending) (void)hipStreamSynchronize(c->last_stream);
+    if (c->last_stream && c->last_stream != c->stream && c->in_flight) (void)hipStreamSynchronize(c->last_stream);
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_geo);
     (void)hipFree(c->d_lgt);
@@ -120,14 +124,17 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_out);
     (void)hipFree(c->d_rays);
     if (c->h_rays) (void)hipHostFree(c->h_rays);
-    if (c->ev_prep0) (void)hipEventDestroy(c->ev_prep0);
-    if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
-    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) {
+        if (c->ev_prep0[i]) (void)hipEventDestroy(c->ev_prep0[i]);
+        if (c->ev_k0[i]) (void)hipEventDestroy(c->ev_k0[i]);
+        if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
 }
 
+int rt_wait(rt_ctx* c);
 static uint32_t local_tiles(const rt_ctx* c) { return rt_tiles_of_rank(c->H, c->rank, c->world); }
 
 uint32_t rt_tiles_of_rank(uint32_t height, uint32_t rank, uint32_t world) {
@@ -272,10 +279,18 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     if (!c->have_spheres) return fail(RT_ERR_STATE, "rt_render: rt_write_spheres has not been called");
     for (int i = 0; i < 6; ++i)
         if (!c->d_face[i]) return fail(RT_ERR_STATE, "rt_render: all six cube map faces must be written first");
-    if (c->pending) return fail(RT_ERR_STATE, "rt_render: previous frame not waited for (one frame in flight, RR:467)");
     RT_HIP(hipSetDevice(c->device));
+    if (c->in_flight && s != c->last_stream) {   // frames in flight stay on one stream
+        int rc = rt_wait(c);
+        if (rc != RT_OK) return rc;
+    }
+    if (c->in_flight == RT355_MAX_IN_FLIGHT) {   // event ring full: drain
+        int rc = rt_wait(c);
+        if (rc != RT_OK) return rc;
+    }
+    const uint32_t slot = c->in_flight;
 
-    RT_HIP(hipEventRecord(c->ev_prep0, s));
+    RT_HIP(hipEventRecord(c->ev_prep0[slot], s));
     if (s != c->stream) c->scene_dirty = true;   // no ordering between streams is assumed
     if (c->scene_dirty && c->n) {
         RtPrepArgs pa;
@@ -299,14 +314,13 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     RtLaunchCfg cfg;
     cfg.variant = c->variant;
 
-    RT_HIP(hipEventRecord(c->ev_k0, s));
+    RT_HIP(hipEventRecord(c->ev_k0[slot], s));
     if (c->mode == RT_MODE_STRICT) RT_HIP(rt_launch_trace_strict(fa, cfg, s));
     else                           RT_HIP(rt_launch_trace_fast(fa, cfg, s));
-    RT_HIP(hipEventRecord(c->ev_k1, s));
+    RT_HIP(hipEventRecord(c->ev_k1[slot], s));
     RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     c->last_stream = s;
-    c->pending = true;
-    c->timed = true;
+    c->in_flight = slot + 1;
     return RT_OK;
 }
 
@@ -327,14 +341,21 @@ int rt_wait(rt_ctx* c) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_wait: ctx is NULL");
     RT_HIP(hipSetDevice(c->device));
     RT_HIP(hipStreamSynchronize(c->last_stream));
-    if (c->pending) {
-        c->pending = false;
-        c->stats.frames += 1;
+    if (c->in_flight) {
+        c->stats.frames += c->in_flight;
         c->stats.rays = *c->h_rays;
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->ev_k0, c->ev_k1) == hipSuccess) c->stats.kernel_ms = ms;
-        if (hipEventElapsedTime(&ms, c->ev_prep0, c->ev_k0) == hipSuccess) c->stats.prep_ms = ms;
+        c->stats.batch_frames = c->in_flight;
+        c->stats.batch_kernel_ms = 0.0f;
+        for (uint32_t i = 0; i < c->in_flight; ++i) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, c->ev_k0[i], c->ev_k1[i]) == hipSuccess) {
+                c->stats.kernel_ms = ms;
+                c->stats.batch_kernel_ms += ms;
+            }
+            if (hipEventElapsedTime(&ms, c->ev_prep0[i], c->ev_k0[i]) == hipSuccess) c->stats.prep_ms = ms;
+        }
         (void)hipGetLastError();
+        c->in_flight = 0;
     }
     return RT_OK;
 }

@@ -68,9 +68,12 @@ typedef struct rt_stats {
     uint64_t rays;                /* scene traversals of the last completed render:
                                      primary/reflection (RK:114) + shadow (RK:153) rays    */
     float kernel_ms;              /* hipEvent time of the last ray-trace kernel launch     */
-    float prep_ms;                /* hipEvent time of the per-frame scene preparation      */
+    float prep_ms;                /* hipEvent time of the last per-frame scene preparation  */
     uint32_t frames;              /* completed renders since rt_create                     */
     int mode;                     /* rt_mode in effect                                     */
+    uint32_t batch_frames;        /* renders completed by the last rt_wait                  */
+    float batch_kernel_ms;        /* sum of their ray-trace kernel times (hipEvents on the
+                                     stream each kernel was launched on)                    */
 } rt_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------- */
@@ -138,7 +141,10 @@ uint32_t rt_padded_tiles(uint32_t height, uint32_t world);
 
 /* Replaces beginComputePass/setPipeline/setBindGroup/dispatchWorkgroups(ceil(W/8),
  * ceil(H/8),1)/submit (RR:442-446, RR:465): enqueues scene preparation + the ray-trace
- * kernel on the context's stream and returns without waiting. */
+ * kernel on the context's stream and returns without waiting.  The reference keeps one
+ * frame in flight (RR:467); this library allows up to RT355_MAX_IN_FLIGHT enqueued frames
+ * (all on one stream, so they execute in order) and drains by itself beyond that. */
+#define RT355_MAX_IN_FLIGHT 32
 int rt_render(rt_ctx* ctx);
 
 /* Replaces `await queue.onSubmittedWorkDone()` (RR:467). */
