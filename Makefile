@@ -4,17 +4,16 @@ ARCH     ?= gfx950
 CSRC     := compute_raytracer_amd/csrc
 LIB      := compute_raytracer_amd/librt355.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-fast-math -Wall -Wno-unused-function
-OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels_strict.o $(CSRC)/rt_kernels_fast.o $(CSRC)/rt_assemble.o
+OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_assemble.o
 
 all: lib oracle node
 
 lib: $(LIB)
 
-$(CSRC)/rt_kernels_strict.o: $(CSRC)/rt_kernels_strict.hip $(CSRC)/rt_kernels.inc $(CSRC)/rt_types.h
-	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
-
-$(CSRC)/rt_kernels_fast.o: $(CSRC)/rt_kernels_fast.hip $(CSRC)/rt_kernels.inc $(CSRC)/rt_types.h
-	$(HIPCC) $(HIPFLAGS) -ffp-contract=fast -c $< -o $@
+# the ray-trace kernels: no FMA contraction, no SLP (packed-math) vectorisation -- see the
+# header of rt_kernels.hip
+$(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_types.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -fno-slp-vectorize -c $< -o $@
 
 $(CSRC)/rt_assemble.o: $(CSRC)/rt_assemble.hip $(CSRC)/rt_types.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

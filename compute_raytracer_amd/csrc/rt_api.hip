@@ -49,7 +49,8 @@ struct rt_ctx {
     float* d_records = nullptr;
     uint32_t n = 0, cap_n = 0;
     bool have_spheres = false;
-    float4 *d_geo = nullptr, *d_lgt = nullptr, *d_cam = nullptr, *d_col = nullptr;
+    float4* d_scene = nullptr;           // 7 arrays of n8 float4: geo lgt cam col geo_f lgt_f cam_f
+    uint32_t n8 = 0;                     // n rounded up to a multiple of 8
     uint8_t* d_face[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
     uint8_t* d_out = nullptr;
@@ -116,10 +117,7 @@ int rt_destroy(rt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->last_stream && c->last_stream != c->stream && c->in_flight) (void)hipStreamSynchronize(c->last_stream);
     (void)hipFree(c->d_records);
-    (void)hipFree(c->d_geo);
-    (void)hipFree(c->d_lgt);
-    (void)hipFree(c->d_cam);
-    (void)hipFree(c->d_col);
+    (void)hipFree(c->d_scene);
     for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
     (void)hipFree(c->d_out);
     (void)hipFree(c->d_rays);
@@ -199,15 +197,12 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
     RT_HIP(hipSetDevice(c->device));
     if (n > c->cap_n) {
         RT_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->d_records); (void)hipFree(c->d_geo); (void)hipFree(c->d_lgt);
-        (void)hipFree(c->d_cam); (void)hipFree(c->d_col);
-        c->d_records = nullptr; c->d_geo = c->d_lgt = c->d_cam = c->d_col = nullptr;
+        (void)hipFree(c->d_records); (void)hipFree(c->d_scene);
+        c->d_records = nullptr; c->d_scene = nullptr;
         c->cap_n = 0;
+        const size_t cap8 = ((size_t)n + 7u) & ~(size_t)7u;
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_records), (size_t)n * 32u));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_geo), (size_t)n * 16u));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_lgt), (size_t)n * 16u));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_cam), (size_t)n * 16u));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_col), (size_t)n * 16u));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scene), cap8 * 7u * sizeof(float4)));
         c->cap_n = n;
     }
     if (n) {
@@ -215,6 +210,7 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
         RT_HIP(hipStreamSynchronize(c->stream));   // caller may free `records` now (writeBuffer semantics)
     }
     c->n = n;
+    c->n8 = (n + 7u) & ~7u;
     c->have_spheres = true;
     c->scene_dirty = true;
     return RT_OK;
@@ -268,7 +264,7 @@ int rt_set_mode(rt_ctx* c, int mode) {
 
 int rt_set_variant(rt_ctx* c, int variant) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_set_variant: ctx is NULL");
-    if (variant < 0 || variant > 4) return fail(RT_ERR_INVALID_ARG, "rt_set_variant: unknown variant");
+    if (variant < 0 || variant > 8) return fail(RT_ERR_INVALID_ARG, "rt_set_variant: unknown variant");
     c->variant = variant;
     return RT_OK;
 }
@@ -295,28 +291,36 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     if (c->scene_dirty && c->n) {
         RtPrepArgs pa;
         std::memcpy(pa.p, c->params, sizeof pa.p);
-        pa.N = c->n;
+        pa.N = c->n; pa.N8 = c->n8;
         pa.records = c->d_records;
-        pa.geo = c->d_geo; pa.lgt = c->d_lgt; pa.cam = c->d_cam; pa.col = c->d_col;
-        RT_HIP(rt_launch_prep_strict(pa, s));
+        float4* b = c->d_scene;
+        pa.geo = b; pa.lgt = b + c->n8; pa.cam = b + 2u * c->n8; pa.col = b + 3u * c->n8;
+        pa.geo_f = b + 4u * c->n8; pa.lgt_f = b + 5u * c->n8; pa.cam_f = b + 6u * c->n8;
+        RT_HIP(rt_launch_prep(pa, s));
     }
     c->scene_dirty = (s != c->stream);
     RT_HIP(hipMemsetAsync(c->d_rays, 0, sizeof(unsigned long long), s));
 
     RtFrameArgs fa;
     std::memcpy(fa.p, c->params, sizeof fa.p);
-    fa.W = c->W; fa.H = c->H; fa.N = c->n;
+    fa.W = c->W; fa.H = c->H; fa.N = c->n; fa.N8 = c->n8;
     fa.tile_first = c->rank; fa.tile_step = c->world; fa.n_local_tiles = local_tiles(c);
-    fa.geo = c->d_geo; fa.lgt = c->d_lgt; fa.cam = c->d_cam; fa.col = c->d_col;
+    {
+        const float4* b = c->d_scene;
+        fa.geo = b; fa.lgt = b + c->n8; fa.cam = b + 2u * c->n8; fa.col = b + 3u * c->n8;
+        fa.geo_f = b + 4u * c->n8; fa.lgt_f = b + 5u * c->n8; fa.cam_f = b + 6u * c->n8;
+    }
+    if ((size_t)c->n8 * 2u * sizeof(float4) > 160u * 1024u)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render: more than 5120 spheres need chunked LDS staging (not built yet)");
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
     fa.out = dst;
     fa.rays = c->d_rays;
     RtLaunchCfg cfg;
+    cfg.mode = c->mode;
     cfg.variant = c->variant;
 
     RT_HIP(hipEventRecord(c->ev_k0[slot], s));
-    if (c->mode == RT_MODE_STRICT) RT_HIP(rt_launch_trace_strict(fa, cfg, s));
-    else                           RT_HIP(rt_launch_trace_fast(fa, cfg, s));
+    RT_HIP(rt_launch_trace(fa, cfg, s));
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
     RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     c->last_stream = s;

@@ -1,0 +1,140 @@
+// rt_device.h -- device-side helpers shared by the gfx950 ray-trace kernels.
+//
+// Everything here evaluates the reference shader's arithmetic in correctly rounded fp32 with
+// no multiply-add fusion (the translation unit is compiled with -ffp-contract=off), in the
+// operation order oracle/rt_oracle.c fixes, so that results are bit-identical to the oracle.
+// Citations are relative to the reference repository:
+//   RK = src/rendering-raycast/shaders/raytracer-kernel.wgsl
+//   HK = src/rendering-raycast/shaders/heatmap-kernel.wgsl
+#pragma once
+#include "rt_types.h"
+
+namespace rtk {
+
+struct v3 { float x, y, z; };
+__device__ __forceinline__ v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+__device__ __forceinline__ v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 scale(float s, v3 a) { return V(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ v3 divs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length(v3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ v3 normalize(v3 a) { return divs(a, length(a)); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// WGSL reflect(e1, e2) = e1 - 2 * dot(e2, e1) * e2
+__device__ __forceinline__ v3 reflect(v3 e1, v3 e2) { return sub(e1, scale(2.0f * dot(e2, e1), e2)); }
+
+// ---- cube map sample: the arithmetic oracle/rt_oracle.c:cube_sample fixes -------------------
+__device__ __forceinline__ v3 texel(const uint8_t* __restrict__ f, int w, int h, int x, int y) {
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+    const uchar4 p = *reinterpret_cast<const uchar4*>(f + 4u * ((size_t)y * (size_t)w + (size_t)x));
+    return V((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f);
+}
+__device__ __forceinline__ v3 lerp3(v3 a, v3 b, float f) { return add(a, scale(f, sub(b, a))); }
+
+__device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r) {
+    const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
+    int face; float sc, tc, ma;
+    if (az >= ax && az >= ay) {
+        if (r.z >= 0.0f) { face = 4; sc = r.x;  tc = -r.y; } else { face = 5; sc = -r.x; tc = -r.y; }
+        ma = az;
+    } else if (ay >= ax) {
+        if (r.y >= 0.0f) { face = 2; sc = r.x; tc = r.z; } else { face = 3; sc = r.x; tc = -r.z; }
+        ma = ay;
+    } else {
+        if (r.x >= 0.0f) { face = 0; sc = -r.z; tc = -r.y; } else { face = 1; sc = r.z; tc = -r.y; }
+        ma = ax;
+    }
+    // per-lane face index: select pointer/size without a runtime-indexed register array
+    const uint8_t* f = A.face[0]; int w = (int)A.fw[0], h = (int)A.fh[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+        if (face == i) { f = A.face[i]; w = (int)A.fw[i]; h = (int)A.fh[i]; }
+    const float s = 0.5f * (sc / ma) + 0.5f;
+    const float t = 0.5f * (tc / ma) + 0.5f;
+    const float u = s * (float)w - 0.5f;
+    const float v = t * (float)h - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float wu = u - fu, wv = v - fv;
+    const int x0 = (int)fu, y0 = (int)fv;
+    const v3 c00 = texel(f, w, h, x0, y0), c10 = texel(f, w, h, x0 + 1, y0);
+    const v3 c01 = texel(f, w, h, x0, y0 + 1), c11 = texel(f, w, h, x0 + 1, y0 + 1);
+    return lerp3(lerp3(c00, c10, wu), lerp3(c01, c11, wu), wv);
+}
+
+__device__ __forceinline__ uint32_t unorm8(float c) {
+    if (!(c == c)) return 0u;
+    c = clampf(c, 0.0f, 1.0f);
+    return (uint32_t)floorf(c * 255.0f + 0.5f);
+}
+
+// ---- frame constants unpacked from the kernarg copy of SceneParameters (RK:2-11) -------------
+struct Scene {
+    v3 cameraPos, forwards, right, up, lightPos;
+    float lightIntensity, minIntensity;
+    uint32_t bounces;
+};
+__device__ __forceinline__ Scene unpack_scene(const RtFrameArgs& A) {
+    Scene s;
+    s.cameraPos = V(A.p[0], A.p[1], A.p[2]);
+    s.forwards = V(A.p[4], A.p[5], A.p[6]);
+    s.right = V(A.p[8], A.p[9], A.p[10]);
+    s.up = V(A.p[12], A.p[13], A.p[14]);
+    s.lightPos = V(A.p[16], A.p[17], A.p[18]);
+    s.lightIntensity = A.p[19];
+    s.minIntensity = A.p[20];
+    const float mb = A.p[21];   // u32(scene.maxBounces), RK:110: truncating, saturating
+    s.bounces = 0;
+    if (mb > 0.0f) s.bounces = mb >= 4294967040.0f ? 4294967295u : (uint32_t)mb;
+    return s;
+}
+
+// RK:78-86
+__device__ __forceinline__ v3 primary_dir(const RtFrameArgs& A, const Scene& sc, uint32_t x, uint32_t y) {
+    const float hc = ((float)(int)x - (float)A.W / 2.0f) / (float)A.W * 2.0f;
+    const float vc = ((float)A.H / 2.0f - (float)(int)y) / (float)A.W * 2.0f;
+    return normalize(add(add(sc.forwards, scale(hc, sc.right)), scale(vc, sc.up)));
+}
+
+// RK:91-98: fog/sky compose and rgba8unorm pack
+__device__ __forceinline__ uint32_t compose_pixel(const RtFrameArgs& A, const Scene& sc, v3 dir0, v3 color, float dist) {
+    const v3 sky = scale(sc.minIntensity, cube_sample(A, dir0));
+    const float k = clampf((30.0f - dist) / 30.0f, 0.0f, 1.0f);
+    const v3 px = add(scale(k, color), scale(1.0f - k, sky));
+    return unorm8(px.x) | (unorm8(px.y) << 8) | (unorm8(px.z) << 16) | 0xFF000000u;
+}
+
+// RK:155-165: the tail of lightIntensity once the shadow ray's nearest hit (st, shit) is known
+__device__ __forceinline__ float light_term(const Scene& sc, v3 dest, v3 normal, v3 sdir, float distance,
+                                            bool shit, float st) {
+    if (shit) {
+        const v3 hp = add(sc.lightPos, scale(st, sdir));         // RK:156
+        const float diff = length(sub(hp, dest));                // RK:157
+        if (diff < 0.005f) {                                     // RK:158-159
+            const float power = clampf(dot(normal, V(-sdir.x, -sdir.y, -sdir.z)), sc.minIntensity, 1.0f);  // RK:160
+            const float cap = sc.lightIntensity / (sc.lightIntensity + distance);                         // RK:161
+            return power * cap;                                  // RK:162
+        }
+    }
+    return sc.minIntensity;                                      // RK:165
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one atomicAdd per wave for the scene-traversal counter
+__device__ __forceinline__ void count_rays(unsigned long long* counter, uint32_t nrays) {
+    const uint64_t live = __ballot(1);
+    if (live == ~0ull) {
+        const uint32_t tot = wave_sum(nrays);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(counter, (unsigned long long)tot);
+    } else {
+        atomicAdd(counter, (unsigned long long)nrays);
+    }
+}
+
+}  // namespace rtk

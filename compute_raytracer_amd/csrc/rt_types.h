@@ -3,42 +3,46 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Relative safety margin of the conservative discriminant filter (see rt_kernels.hip).
+#define RT_FILTER_KAPPA 1.52587890625e-05f   // 2^-16
+
 // One frame's launch arguments (kernarg segment -> SGPRs; everything here is wave-uniform).
 struct RtFrameArgs {
     float p[24];               // SceneParameters as RR:157-165 packs them
     uint32_t W, H, N;          // target size, sphere count
+    uint32_t N8;               // N rounded up to a multiple of 8 (filter arrays are padded to it)
     uint32_t tile_first;       // first 8-row tile of this rank
     uint32_t tile_step;        // world size (tile stride)
     uint32_t n_local_tiles;    // tiles this launch renders
-    const float4* geo;         // [N] {cx, cy, cz, radius*radius}
-    const float4* lgt;         // [N] {L-c (xyz), dot(L-c,L-c) - r*r}   origin = light (shadow rays)
-    const float4* cam;         // [N] same for origin = camera           (primary rays)
-    const float4* col;         // [N] {r, g, b, 0}
+    // exact records, [N]: the values the reference arithmetic consumes
+    const float4* geo;         // {cx, cy, cz, radius*radius}
+    const float4* lgt;         // {L-c (xyz), dot(L-c,L-c) - r*r}   ray origin = light  (shadow rays)
+    const float4* cam;         // same for ray origin = camera       (primary rays)
+    const float4* col;         // {r, g, b, 0}
+    // filter records, [N8]: inflated copies for the conservative discriminant test
+    const float4* geo_f;       // {cx, cy, cz, r*r*(1+kappa)}            pad: w = -inf
+    const float4* lgt_f;       // {L-c (xyz), |L-c|^2 - r*r*(1+kappa)}   pad: w = +inf
+    const float4* cam_f;       // same for the camera
     const uint8_t* face[6];    // cube faces, rgba8unorm
     uint32_t fw[6], fh[6];
     uint8_t* out;              // compact tile buffer [n_local_tiles*8][W][4]
-    unsigned long long* rays;  // scene-traversal counter (atomicAdd once per wave)
+    unsigned long long* rays;  // scene-traversal counter (one atomicAdd per wave)
 };
 
 struct RtPrepArgs {
     float p[24];
-    uint32_t N;
+    uint32_t N, N8;
     const float* records;      // [N][8] {cx,cy,cz,_, r,g,b, radius}
-    float4* geo;
-    float4* lgt;
-    float4* cam;
-    float4* col;
+    float4 *geo, *lgt, *cam, *col;
+    float4 *geo_f, *lgt_f, *cam_f;
 };
 
-// Launch entry points, one pair per arithmetic mode (separate translation units compiled
-// with -ffp-contract=off / =fast).
 struct RtLaunchCfg {
+    int mode;      // rt_mode
     int variant;   // kernel variant id; 0 = default
 };
 
-hipError_t rt_launch_prep_strict(const RtPrepArgs& a, hipStream_t s);
-hipError_t rt_launch_trace_strict(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
-hipError_t rt_launch_trace_fast(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
+hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
+hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t W, uint32_t H,
                               uint32_t world, uint32_t padded_tiles, hipStream_t s);
-const char* rt_variant_name(int variant);

@@ -276,6 +276,15 @@ int rt_oracle_render(const float params[24], const float* spheres, uint32_t n,
                      const rt_oracle_face faces[6], uint32_t W, uint32_t H,
                      uint32_t tile_first, uint32_t tile_step,
                      uint8_t* out_rgba8, float* out_rgb, uint64_t* rays_out, int threads) {
+    return rt_oracle_render_ex(params, spheres, n, faces, W, H, tile_first, tile_step, out_rgba8,
+                               out_rgb, NULL, rays_out, threads);
+}
+
+int rt_oracle_render_ex(const float params[24], const float* spheres, uint32_t n,
+                        const rt_oracle_face faces[6], uint32_t W, uint32_t H,
+                        uint32_t tile_first, uint32_t tile_step,
+                        uint8_t* out_rgba8, float* out_rgb, uint16_t* out_rays_px,
+                        uint64_t* rays_out, int threads) {
     if (!params || !faces || (n && !spheres) || tile_step == 0) return -1;
     for (int f = 0; f < 6; ++f)
         if (!faces[f].rgba || faces[f].w == 0 || faces[f].h == 0) return -2;
@@ -297,8 +306,10 @@ int rt_oracle_render(const float params[24], const float* spheres, uint32_t n,
         uint64_t rays = 0;
         for (uint32_t x = 0; x < W; ++x) {
             float rgb[3];
+            uint64_t before = rays;
             shade_pixel(&sc, spheres, n, faces, W, H, x, y, rgb, &rays);
             size_t idx = (size_t)y * W + x;
+            if (out_rays_px) out_rays_px[idx] = (uint16_t)(rays - before);
             if (out_rgb) {
                 out_rgb[3 * idx + 0] = rgb[0];
                 out_rgb[3 * idx + 1] = rgb[1];

@@ -85,6 +85,14 @@ int rt_oracle_render(const float params[24], const float* spheres, uint32_t n,
                      uint32_t tile_first, uint32_t tile_step,
                      uint8_t* out_rgba8, float* out_rgb, uint64_t* rays_out, int threads);
 
+/* As rt_oracle_render, additionally writing the number of scene traversals of each rendered
+ * pixel to out_rays_px[y*W + x] (may be NULL). */
+int rt_oracle_render_ex(const float params[24], const float* spheres, uint32_t n,
+                        const rt_oracle_face faces[6], uint32_t W, uint32_t H,
+                        uint32_t tile_first, uint32_t tile_step,
+                        uint8_t* out_rgba8, float* out_rgb, uint16_t* out_rays_px,
+                        uint64_t* rays_out, int threads);
+
 int rt_oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -35,6 +35,11 @@ def lib():
         L.rt_oracle_render.argtypes = [fp, fp, ctypes.c_uint32, ctypes.POINTER(_Face), ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+        L.rt_oracle_render_ex.restype = ctypes.c_int
+        L.rt_oracle_render_ex.argtypes = [fp, fp, ctypes.c_uint32, ctypes.POINTER(_Face), ctypes.c_uint32,
+                                          ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
+                                          ctypes.c_int]
         L.rt_oracle_hit_sphere.restype = _Hit
         L.rt_oracle_hit_sphere.argtypes = [fp, fp, fp, ctypes.c_float, ctypes.c_float]
         L.rt_oracle_ray_dir.restype = None
@@ -77,6 +82,21 @@ def render(params, spheres, faces, W, H, tile_first=0, tile_step=1, want_float=F
     if rc != 0:
         raise RuntimeError("rt_oracle_render failed: %d" % rc)
     return out, outf, rays.value
+
+
+def render_ray_counts(params, spheres, faces, W, H, threads=0):
+    """Per-pixel scene-traversal counts (H,W) uint16 and the RGBA8 frame."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 8)
+    arr, keep = _faces(faces)
+    out = np.zeros((H, W, 4), dtype=np.uint8)
+    cnt = np.zeros((H, W), dtype=np.uint16)
+    rays = ctypes.c_uint64(0)
+    rc = lib().rt_oracle_render_ex(_fp(params), _fp(spheres), spheres.shape[0], arr, W, H, 0, 1,
+                                   out.ctypes.data, None, cnt.ctypes.data, ctypes.byref(rays), threads)
+    if rc != 0:
+        raise RuntimeError("rt_oracle_render_ex failed: %d" % rc)
+    return out, cnt, rays.value
 
 
 def hit_sphere(origin, direction, sphere, t_min, t_max):
