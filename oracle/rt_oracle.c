@@ -264,6 +264,15 @@ static void shade_pixel(const scene_params* sc, const float* spheres, uint32_t n
     rgb[0] = pixel.x; rgb[1] = pixel.y; rgb[2] = pixel.z;
 }
 
+void rt_oracle_pixel(const float params[24], const float* spheres, uint32_t n,
+                     const rt_oracle_face faces[6], uint32_t W, uint32_t H, uint32_t x, uint32_t y,
+                     float rgb[3], uint64_t* rays) {
+    scene_params sc = unpack(params);
+    uint64_t r = 0;
+    shade_pixel(&sc, spheres, n, faces, W, H, x, y, rgb, &r);
+    if (rays) *rays += r;
+}
+
 int rt_oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

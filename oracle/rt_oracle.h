@@ -93,6 +93,12 @@ int rt_oracle_render_ex(const float params[24], const float* spheres, uint32_t n
                         uint8_t* out_rgba8, float* out_rgb, uint16_t* out_rays_px,
                         uint64_t* rays_out, int threads);
 
+/* RK:73-99 for the single pixel (x,y): pre-quantisation pixelColor; adds its scene
+ * traversals to *rays (may be NULL). */
+void rt_oracle_pixel(const float params[24], const float* spheres, uint32_t n,
+                     const rt_oracle_face faces[6], uint32_t W, uint32_t H, uint32_t x, uint32_t y,
+                     float rgb[3], uint64_t* rays);
+
 int rt_oracle_max_threads(void);
 
 #ifdef __cplusplus

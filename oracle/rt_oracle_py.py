@@ -51,6 +51,9 @@ def lib():
         L.rt_oracle_ray_color.restype = None
         L.rt_oracle_ray_color.argtypes = [fp, fp, ctypes.c_uint32, ctypes.POINTER(_Face), fp, fp, fp,
                                           ctypes.POINTER(ctypes.c_uint64)]
+        L.rt_oracle_pixel.restype = None
+        L.rt_oracle_pixel.argtypes = [fp, fp, ctypes.c_uint32, ctypes.POINTER(_Face), ctypes.c_uint32, ctypes.c_uint32,
+                                      ctypes.c_uint32, ctypes.c_uint32, fp, ctypes.POINTER(ctypes.c_uint64)]
         L.rt_oracle_max_threads.restype = ctypes.c_int
         _LIB = L
     return _LIB
@@ -136,6 +139,17 @@ def ray_color(params, spheres, faces, origin, direction):
     rays = ctypes.c_uint64(0)
     lib().rt_oracle_ray_color(_fp(params), _fp(spheres), spheres.shape[0], arr, _fp(o), _fp(d), _fp(out),
                               ctypes.byref(rays))
+    return out, rays.value
+
+
+def pixel(params, spheres, faces, W, H, x, y):
+    """(rgb float32[3] before quantisation, scene traversals) of one pixel."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 8)
+    arr, keep = _faces(faces)
+    out = np.zeros(3, np.float32)
+    rays = ctypes.c_uint64(0)
+    lib().rt_oracle_pixel(_fp(params), _fp(spheres), spheres.shape[0], arr, W, H, x, y, _fp(out), ctypes.byref(rays))
     return out, rays.value
 
 

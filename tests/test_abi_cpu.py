@@ -1,0 +1,81 @@
+"""The C-ABI library on a machine without a GPU: it loads, exports every symbol that
+include/rt355.h declares, refuses to work without a device (no CPU fallback) and its pure
+helper functions agree with the Python host logic."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import compute_raytracer_amd as rt
+from compute_raytracer_amd import abi, tiles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = abi.load()
+    names = header_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "librt355.so does not export %s" % n
+    assert sorted(abi.SYMBOLS) == names, "abi.SYMBOLS is out of sync with include/rt355.h"
+    assert lib.rt_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = abi.load()
+    ctx = ctypes.c_void_p()
+    rc = lib.rt_create(0, ctypes.byref(ctx))
+    assert rc == abi.RT_ERR_NO_DEVICE and not ctx.value
+    assert b"no CPU path" in lib.rt_last_error(None)
+    r = rt.RendererRaytracing(64, 64, rt.synthetic_scene(3, 1))
+    with pytest.raises(abi.RtError) as e:
+        r.initialize()
+    assert e.value.code == abi.RT_ERR_NO_DEVICE
+
+
+def test_null_arguments_are_rejected():
+    lib = abi.load()
+    assert lib.rt_create(0, None) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_resize(None, 8, 8) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_render(None) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_wait(None) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_destroy(None) == abi.RT_OK
+    assert b"NULL" in lib.rt_last_error(None)
+
+
+def test_triangle_path_reports_unsupported():
+    lib = abi.load()
+    assert lib.rt_write_triangles(None, None, 0) == abi.RT_ERR_UNSUPPORTED
+    assert lib.rt_write_nodes(None, 0, None, 0) == abi.RT_ERR_UNSUPPORTED
+    assert lib.rt_write_blas(None, None, 0) == abi.RT_ERR_UNSUPPORTED
+    assert lib.rt_write_tri_lookup(None, None, 0) == abi.RT_ERR_UNSUPPORTED
+    assert lib.rt_write_blas_lookup(None, None, 0) == abi.RT_ERR_UNSUPPORTED
+    assert lib.rt_write_mesh_texture(None, 0, 0, None) == abi.RT_ERR_UNSUPPORTED
+    assert b"8(f)" in lib.rt_last_error(None)
+
+
+@pytest.mark.parametrize("H", [1, 7, 8, 9, 256, 1080, 2160, 4320, 53])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_tile_arithmetic_matches_host(H, world):
+    lib = abi.load()
+    total = 0
+    for r in range(world):
+        n = lib.rt_tiles_of_rank(H, r, world)
+        assert n == tiles.tiles_of_rank(H, r, world)
+        assert n == len([t for t in range(tiles.total_tiles(H)) if t % world == r])
+        total += n
+    assert total == tiles.total_tiles(H)
+    assert lib.rt_padded_tiles(H, world) == tiles.padded_tiles(H, world) == max(
+        tiles.tiles_of_rank(H, r, world) for r in range(world))
+    assert lib.rt_tiles_of_rank(H, world, world) == 0 and lib.rt_padded_tiles(H, 0) == 0

@@ -1,0 +1,63 @@
+"""The oracle against the committed golden vectors (tests/golden/, written by make_golden.py
+from this same oracle: regression pins, not outputs of the reference -- PARITY UNPINNED)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import compute_raytracer_amd as rt
+from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return json.load(open(os.path.join(G, name)))
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3"])
+def test_scene_generator_kat(name):
+    g = load("scene_%s.json" % name)
+    cfg = rt.BASELINE_CONFIGS[name]
+    scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
+    p, s = scene.pack_params(cfg["bounces"]), scene.pack_spheres()
+    assert [int(v) for v in p.view(np.uint32)] == g["params_bits"]
+    assert [int(v) for v in s[:3].reshape(-1).view(np.uint32)] == g["first"]
+    assert [int(v) for v in s[-1].view(np.uint32)] == g["last"]
+    assert hashlib.sha256(s.tobytes()).hexdigest() == g["sha256"]
+
+
+def test_c1_full_frame(oracle, constant_sky):
+    from PIL import Image
+    want = np.array(Image.open(os.path.join(G, "c1_frame.png")).convert("RGBA"), dtype=np.uint8)
+    cfg = rt.BASELINE_CONFIGS["C1"]
+    scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
+    img, _, rays = oracle.render(scene.pack_params(cfg["bounces"]), scene.pack_spheres(), constant_sky.faces,
+                                 cfg["width"], cfg["height"])
+    fr = load("frames.json")["C1"]
+    assert np.array_equal(img, want)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == fr["sha256"] and rays == fr["rays"]
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3"])
+def test_sparse_pixels(oracle, constant_sky, name):
+    g = load("sparse_%s.json" % name)
+    cfg = rt.BASELINE_CONFIGS[name]
+    scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
+    p, s = scene.pack_params(cfg["bounces"]), scene.pack_spheres()
+    for px in g["pixels"]:
+        rgb, rays = oracle.pixel(p, s, constant_sky.faces, cfg["width"], cfg["height"], px["x"], px["y"])
+        assert [int(v) for v in rgb.view(np.uint32)] == px["rgb_bits"], px
+        assert rays == px["rays"]
+        assert [oracle.unorm8(c) for c in rgb] + [255] == px["rgba8"]
+
+
+def test_c2_full_frame_hash(oracle, constant_sky):
+    cfg = rt.BASELINE_CONFIGS["C2"]
+    scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
+    img, _, rays = oracle.render(scene.pack_params(cfg["bounces"]), scene.pack_spheres(), constant_sky.faces,
+                                 cfg["width"], cfg["height"])
+    fr = load("frames.json")["C2"]
+    assert hashlib.sha256(img.tobytes()).hexdigest() == fr["sha256"] and rays == fr["rays"]

@@ -1,0 +1,77 @@
+"""The N>1 host path (row-tile partition -> all-gather -> de-interleave) with world_size 2 and 3
+over gloo on the CPU.  The per-rank pixel data comes from the CPU oracle standing in for the
+HIP renderer (test infrastructure); what is under test is compute_raytracer_amd.tiles, the
+logic bench.py and the GPU path share.  The gathered frame must be byte-identical to the
+1-rank frame."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import compute_raytracer_amd as rt
+from compute_raytracer_amd import tiles
+from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, W, H, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import rt_oracle_py as orc
+        scene = rt.synthetic_scene(12, 4242)
+        sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+        p, s = scene.pack_params(3), scene.pack_spheres()
+        # this rank's tiles, as the renderer would leave them: compact [padded_tiles][8][W][4]
+        part, _, rays = orc.render(p, s, sky.faces, W, H, tile_first=rank, tile_step=world, threads=1)
+        pt = tiles.padded_tiles(H, world)
+        local = np.zeros((pt, 8, W, 4), np.uint8)
+        for j in range(tiles.tiles_of_rank(H, rank, world)):
+            y0 = (rank + j * world) * 8
+            rows = min(8, H - y0)
+            local[j, :rows] = part[y0:y0 + rows]
+        t = torch.from_numpy(local.reshape(-1))
+        assert t.numel() == tiles.message_bytes(W, H, world)
+        gathered = tiles.all_gather_frame(t, W, H)
+        frame = tiles.assemble_torch(gathered, W, H, world).numpy()
+        frame2 = tiles.assemble_numpy(gathered.numpy(), W, H, world)
+        full, _, full_rays = orc.render(p, s, sky.faces, W, H, threads=1)
+        rays_t = torch.tensor([rays], dtype=torch.int64)
+        dist.all_reduce(rays_t)
+        ok = np.array_equal(frame, full) and np.array_equal(frame2, full) and int(rays_t[0]) == full_rays
+        open(os.path.join(result_dir, "rank%d" % rank), "w").write("ok" if ok else "MISMATCH")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 40, 64), (2, 24, 53), (3, 16, 100)])
+def test_gather_is_byte_identical_to_single_rank(tmp_path, world, W, H):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, W, H, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"
+
+
+def test_assemble_round_trip_single_process():
+    rng = np.random.default_rng(3)
+    for (W, H, world) in [(8, 8, 1), (5, 53, 4), (12, 2160 // 8, 8), (3, 17, 2)]:
+        frame = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+        pt = tiles.padded_tiles(H, world)
+        g = np.zeros((world, pt, 8, W, 4), np.uint8)
+        for y in range(H):
+            r, j = tiles.owner_of_row(y, world)
+            g[r, j, y & 7] = frame[y]
+        assert np.array_equal(tiles.assemble_numpy(g, W, H, world), frame)
+        assert np.array_equal(tiles.assemble_torch(torch.from_numpy(g.reshape(-1)), W, H, world).numpy(), frame)
