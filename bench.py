@@ -51,19 +51,20 @@ def cpu_baseline(cfg, scene, sky, target_s):
     from oracle import rt_oracle_py as orc
     W, H, B = cfg["width"], cfg["height"], cfg["bounces"]
     p, s = scene.pack_params(B), scene.pack_spheres()
-    threads = orc.max_threads()
+    # the GPU box's CPU share for one GPU is 16 hardware threads; never use more than that
+    threads = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0)), 16))
     ntiles = (H + 7) // 8
     # calibrate on a thin sample, then size the timed sample for ~target_s seconds
     step0 = max(1, ntiles // 4)
     t0 = time.perf_counter()
-    _, _, rays0 = orc.render(p, s, sky.faces, W, H, tile_first=step0 // 2, tile_step=step0)
+    _, _, rays0 = orc.render(p, s, sky.faces, W, H, tile_first=step0 // 2, tile_step=step0, threads=threads)
     dt0 = time.perf_counter() - t0
     n0 = len(range(step0 // 2, ntiles, step0))
     per_tile = dt0 / max(n0, 1)
     want = max(1, min(ntiles, int(target_s / max(per_tile, 1e-9))))
     step = max(1, ntiles // want)
     t0 = time.perf_counter()
-    _, _, rays = orc.render(p, s, sky.faces, W, H, tile_first=step // 2, tile_step=step)
+    _, _, rays = orc.render(p, s, sky.faces, W, H, tile_first=step // 2, tile_step=step, threads=threads)
     dt = time.perf_counter() - t0
     n = len(range(step // 2, ntiles, step))
     return {

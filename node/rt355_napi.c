@@ -1,0 +1,317 @@
+/*
+ * rt355_napi.c -- thin Node N-API shim over the C ABI of librt355.so (include/rt355.h).
+ *
+ * It takes the place of the WebGPU object model the reference's RendererRaytracing talks to
+ * (src/rendering-raycast/renderer-raytracing.ts): every exported function is one C-ABI call;
+ * the mapping to the reference's WebGPU calls is documented in include/rt355.h.
+ * Plain C against /usr/include/node/node_api.h (N-API v8, Node >= 12.22), no node-gyp.
+ *
+ *   const rt = require('./rt355.node');
+ *   const ctx = rt.create(0);  rt.resize(ctx, w, h);  rt.writeParams(ctx, Float32Array(24)); ...
+ *   rt.render(ctx);            // enqueue (RR:442-446, 465)
+ *   await rt.wait(ctx);        // promise resolved from a worker thread (RR:467)
+ *
+ * Errors: a non-zero rt_status becomes a thrown JS Error (synchronous calls) or a rejected
+ * promise (wait), with rt_last_error() as the message and `.code` = the status.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rt355.h"
+
+#define NAPI_OK(call)                                                     \
+    do {                                                                  \
+        if ((call) != napi_ok) {                                          \
+            napi_throw_error(env, NULL, "rt355: N-API call failed: " #call); \
+            return NULL;                                                  \
+        }                                                                 \
+    } while (0)
+
+static napi_value throw_status(napi_env env, int rc, rt_ctx* ctx) {
+    char code[16];
+    snprintf(code, sizeof code, "%d", rc);
+    const char* msg = rt_last_error(ctx);
+    napi_throw_error(env, code, (msg && *msg) ? msg : "rt355 error");
+    return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        napi_throw_type_error(env, NULL, "rt355: missing arguments");
+        return 0;
+    }
+    return 1;
+}
+
+static rt_ctx* get_ctx(napi_env env, napi_value v) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "rt355: first argument must be a context from create()");
+        return NULL;
+    }
+    return (rt_ctx*)p;
+}
+
+static int get_u32(napi_env env, napi_value v, uint32_t* out) {
+    if (napi_get_value_uint32(env, v, out) != napi_ok) {
+        napi_throw_type_error(env, NULL, "rt355: expected an unsigned integer");
+        return 0;
+    }
+    return 1;
+}
+
+static int get_i32(napi_env env, napi_value v, int32_t* out) {
+    if (napi_get_value_int32(env, v, out) != napi_ok) {
+        napi_throw_type_error(env, NULL, "rt355: expected an integer");
+        return 0;
+    }
+    return 1;
+}
+
+/* typed array -> pointer + element count, checking the element type */
+static int get_typed(napi_env env, napi_value v, napi_typedarray_type want, void** data, size_t* len) {
+    napi_typedarray_type t;
+    napi_value ab;
+    size_t off;
+    bool is = false;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is ||
+        napi_get_typedarray_info(env, v, &t, len, data, &ab, &off) != napi_ok || t != want) {
+        napi_throw_type_error(env, NULL, want == napi_float32_array ? "rt355: expected a Float32Array"
+                                                                     : "rt355: expected a Uint8Array");
+        return 0;
+    }
+    return 1;
+}
+
+static napi_value undefined(napi_env env) {
+    napi_value u;
+    napi_get_undefined(env, &u);
+    return u;
+}
+
+/* create(device) -> external */
+static napi_value Create(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    int32_t dev = 0;
+    if (!get_args(env, info, 1, argv) || !get_i32(env, argv[0], &dev)) return NULL;
+    rt_ctx* ctx = NULL;
+    int rc = rt_create(dev, &ctx);
+    if (rc != RT_OK) return throw_status(env, rc, NULL);
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, ctx, NULL, NULL, &ext));
+    return ext;
+}
+
+static napi_value Destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    rt_destroy(ctx);
+    return undefined(env);
+}
+
+static napi_value Resize(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    uint32_t w, h;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_u32(env, argv[1], &w) || !get_u32(env, argv[2], &h)) return NULL;
+    int rc = rt_resize(ctx, w, h);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value WriteParams(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    void* data; size_t len;
+    if (!get_args(env, info, 2, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_typed(env, argv[1], napi_float32_array, &data, &len)) return NULL;
+    if (len != 24) { napi_throw_range_error(env, NULL, "rt355: params must be a Float32Array(24) (RR:158)"); return NULL; }
+    int rc = rt_write_params(ctx, (const float*)data);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value WriteSpheres(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    void* data; size_t len;
+    if (!get_args(env, info, 2, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_typed(env, argv[1], napi_float32_array, &data, &len)) return NULL;
+    if (len % 8) { napi_throw_range_error(env, NULL, "rt355: sphere records are 8 floats each"); return NULL; }
+    int rc = rt_write_spheres(ctx, (const float*)data, (uint32_t)(len / 8));
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value WriteCubemapFace(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    int32_t face; uint32_t w, h;
+    void* data; size_t len;
+    if (!get_args(env, info, 5, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_i32(env, argv[1], &face) || !get_u32(env, argv[2], &w) || !get_u32(env, argv[3], &h) ||
+        !get_typed(env, argv[4], napi_uint8_array, &data, &len))
+        return NULL;
+    if (len != (size_t)w * h * 4) { napi_throw_range_error(env, NULL, "rt355: face needs w*h*4 bytes"); return NULL; }
+    int rc = rt_write_cubemap_face(ctx, face, w, h, (const uint8_t*)data);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+#define INT_SETTER(NAME, CALL)                                                 \
+    static napi_value NAME(napi_env env, napi_callback_info info) {            \
+        napi_value argv[2];                                                    \
+        int32_t v;                                                             \
+        if (!get_args(env, info, 2, argv)) return NULL;                        \
+        rt_ctx* ctx = get_ctx(env, argv[0]);                                   \
+        if (!ctx || !get_i32(env, argv[1], &v)) return NULL;                   \
+        int rc = CALL(ctx, v);                                                 \
+        return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);      \
+    }
+INT_SETTER(SelectKernel, rt_select_kernel)
+INT_SETTER(SetMode, rt_set_mode)
+INT_SETTER(SetVariant, rt_set_variant)
+
+static napi_value SetPartition(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    uint32_t rank, world;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_u32(env, argv[1], &rank) || !get_u32(env, argv[2], &world)) return NULL;
+    int rc = rt_set_partition(ctx, rank, world);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value Render(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int rc = rt_render(ctx);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+/* wait(ctx) -> Promise<void>: rt_wait on a libuv worker so the JS loop is not blocked */
+typedef struct {
+    rt_ctx* ctx;
+    int rc;
+    char msg[256];
+    napi_deferred deferred;
+    napi_async_work work;
+} wait_job;
+
+static void wait_execute(napi_env env, void* data) {
+    (void)env;
+    wait_job* j = (wait_job*)data;
+    j->rc = rt_wait(j->ctx);
+    if (j->rc != RT_OK) {   /* rt_last_error is thread-local: fetch it on this thread */
+        strncpy(j->msg, rt_last_error(j->ctx), sizeof j->msg - 1);
+        j->msg[sizeof j->msg - 1] = 0;
+    }
+}
+
+static void wait_complete(napi_env env, napi_status status, void* data) {
+    wait_job* j = (wait_job*)data;
+    if (status == napi_ok && j->rc == RT_OK) {
+        napi_resolve_deferred(env, j->deferred, undefined(env));
+    } else {
+        napi_value msg, err;
+        napi_create_string_utf8(env, j->rc != RT_OK ? j->msg : "rt355: wait was cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j);
+}
+
+static napi_value Wait(napi_env env, napi_callback_info info) {
+    napi_value argv[1], promise, name;
+    if (!get_args(env, info, 1, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    wait_job* j = (wait_job*)calloc(1, sizeof *j);
+    if (!j) { napi_throw_error(env, NULL, "rt355: out of memory"); return NULL; }
+    j->ctx = ctx;
+    NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+    NAPI_OK(napi_create_string_utf8(env, "rt355.wait", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, NULL, name, wait_execute, wait_complete, j, &j->work));
+    NAPI_OK(napi_queue_async_work(env, j->work));
+    return promise;
+}
+
+static napi_value WaitSync(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int rc = rt_wait(ctx);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value ReadPixels(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    void* data; size_t len;
+    if (!get_args(env, info, 2, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_typed(env, argv[1], napi_uint8_array, &data, &len)) return NULL;
+    int rc = rt_read_pixels(ctx, (uint8_t*)data, len);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static void set_num(napi_env env, napi_value obj, const char* key, double v) {
+    napi_value n;
+    napi_create_double(env, v, &n);
+    napi_set_named_property(env, obj, key, n);
+}
+
+static napi_value Stats(napi_env env, napi_callback_info info) {
+    napi_value argv[1], obj;
+    if (!get_args(env, info, 1, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    rt_stats st;
+    int rc = rt_get_stats(ctx, &st);
+    if (rc != RT_OK) return throw_status(env, rc, ctx);
+    NAPI_OK(napi_create_object(env, &obj));
+    set_num(env, obj, "width", st.width);
+    set_num(env, obj, "height", st.height);
+    set_num(env, obj, "localTiles", st.local_tiles);
+    set_num(env, obj, "spheres", st.spheres);
+    set_num(env, obj, "rays", (double)st.rays);
+    set_num(env, obj, "kernelMs", st.kernel_ms);
+    set_num(env, obj, "prepMs", st.prep_ms);
+    set_num(env, obj, "frames", st.frames);
+    set_num(env, obj, "mode", st.mode);
+    return obj;
+}
+
+static napi_value AbiVersion(napi_env env, napi_callback_info info) {
+    (void)info;
+    napi_value n;
+    napi_create_int32(env, rt_abi_version(), &n);
+    return n;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+    static const struct { const char* name; napi_callback fn; } fns[] = {
+        {"create", Create}, {"destroy", Destroy}, {"resize", Resize}, {"writeParams", WriteParams},
+        {"writeSpheres", WriteSpheres}, {"writeCubemapFace", WriteCubemapFace}, {"selectKernel", SelectKernel},
+        {"setMode", SetMode}, {"setVariant", SetVariant}, {"setPartition", SetPartition}, {"render", Render},
+        {"wait", Wait}, {"waitSync", WaitSync}, {"readPixels", ReadPixels}, {"stats", Stats},
+        {"abiVersion", AbiVersion},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||
+            napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) {
+            napi_throw_error(env, NULL, "rt355: cannot export function");
+            return NULL;
+        }
+    }
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

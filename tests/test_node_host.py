@@ -1,0 +1,81 @@
+"""The Node host layer (node/*.js + the N-API shim rt355.node) -- the north_star's drop-in shape:
+a TypeScript-like host calling HIP through a thin C-ABI addon.  Skipped when no `node` binary
+is installed.  The GPU cases render BASELINE configs through Node and compare the frame hash
+with the golden hashes of the oracle's frames."""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import compute_raytracer_amd as rt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+ADDON = os.path.join(ROOT, "node", "rt355.node")
+pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON), reason="node or rt355.node not available")
+
+
+def run_node(script, *args, check=True):
+    return subprocess.run([NODE, "-e", script] + list(args), cwd=ROOT, capture_output=True, text=True, check=check,
+                          timeout=300)
+
+
+def test_addon_loads_and_exports():
+    out = run_node("const rt=require('./node/rt355.node');console.log(JSON.stringify([Object.keys(rt).sort(),rt.abiVersion()]))")
+    names, ver = json.loads(out.stdout)
+    assert ver == 1
+    for n in ["create", "destroy", "resize", "writeParams", "writeSpheres", "writeCubemapFace", "selectKernel",
+              "setMode", "setPartition", "render", "wait", "readPixels", "stats"]:
+        assert n in names
+
+
+def test_addon_argument_checks():
+    out = run_node("""
+const rt=require('./node/rt355.node'); const r=[];
+for (const f of [()=>rt.resize(1,2,3), ()=>rt.writeParams({}, new Float32Array(24)), ()=>rt.create('x')]) {
+  try { f(); r.push('no throw'); } catch (e) { r.push(e.constructor.name); } }
+console.log(JSON.stringify(r));""")
+    assert json.loads(out.stdout) == ["TypeError", "TypeError", "TypeError"]
+
+
+def test_js_scene_generator_and_camera_match_python():
+    out = run_node("""
+const s=require('./node/scene-raytracing'); const {Camera}=require('./node/camera');
+const sp=s.syntheticSpheres(64,357); const a=new Float32Array(8*sp.length);
+for (let i=0;i<sp.length;++i){a.set(sp[i].center,8*i);a.set(sp[i].color,8*i+4);a[8*i+7]=sp[i].radius;}
+const c=new Camera([0.0593,2.692,3.293],106,270); c.spin(7,-3); c.move(0.25,-0.1);
+const p=new Float32Array(12); p.set(c.position,0); p.set(c.forwards,3); p.set(c.right,6); p.set(c.up,9);
+console.log(JSON.stringify([Array.from(new Uint32Array(a.buffer)), Array.from(new Uint32Array(p.buffer))]));""")
+    sph_bits, cam_bits = json.loads(out.stdout)
+    scene = rt.synthetic_scene(64, 357)
+    assert sph_bits == [int(v) for v in scene.pack_spheres().reshape(-1).view(np.uint32)]
+    cam = scene.camera
+    cam.spin(7, -3); cam.move(0.25, -0.1)
+    want = np.concatenate([np.array(cam.position).astype(np.float32), cam.forwards, cam.right, cam.up])
+    assert cam_bits == [int(v) for v in want.view(np.uint32)]
+
+
+def test_no_cpu_fallback_in_node():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    out = run_node("const rt=require('./node/rt355.node');try{rt.create(0);console.log('created')}catch(e){console.log(e.code+'|'+e.message)}")
+    assert out.stdout.startswith("-2|") and "no CPU path" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode", [("C1", "fast"), ("C1", "strict"), ("C2", "fast")])
+def test_node_renders_baseline_config(tmp_path, name, mode):
+    fr = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))[name]
+    raw = str(tmp_path / "frame.rgba")
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "app.js"), name, raw, "2", mode], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["sha256"] == fr["sha256"] and res["rays"] == fr["rays"] and res["frames"] == 2
+    data = open(raw, "rb").read()
+    assert len(data) == fr["width"] * fr["height"] * 4 and hashlib.sha256(data).hexdigest() == fr["sha256"]
