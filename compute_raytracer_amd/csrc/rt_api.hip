@@ -5,6 +5,7 @@
 #include "../../include/rt355.h"
 #include "rt_types.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -49,13 +50,16 @@ struct rt_ctx {
     float* d_records = nullptr;
     uint32_t n = 0, cap_n = 0;
     bool have_spheres = false;
-    float4* d_scene = nullptr;           // 7 arrays of n8 float4: geo lgt cam col geo_f lgt_f cam_f
-    uint32_t n8 = 0;                     // n rounded up to a multiple of 8
+    float4* d_scene = nullptr;           // 8 float4 arrays of n16: geo lgt cam col geo_f lgt_f cam_f + {geo_w,lgt_w,cam_w,-}
+    uint32_t n16 = 0;                    // n rounded up to a multiple of 16
+    float scene_bound = 0.0f;            // max over spheres of |center| + radius (host side)
     uint8_t* d_face[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
     uint8_t* d_out = nullptr;
     size_t out_bytes = 0;
-    unsigned long long* d_rays = nullptr;
+    unsigned long long* d_rays = nullptr;  // 16-byte control block: rays (u64), queue count, queue head
+    float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
+    size_t queue_cap = 0;                  // entries
     unsigned long long* h_rays = nullptr;  // pinned
     int mode = RT_MODE_FAST;
     int variant = 0;
@@ -99,7 +103,7 @@ int rt_create(int device, rt_ctx** out) {
         err = hipEventCreate(&c->ev_k1[i]);
     }
     if (err != hipSuccess ||
-        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), sizeof(unsigned long long))) != hipSuccess ||
+        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), 16)) != hipSuccess ||
         (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), sizeof(unsigned long long), hipHostMallocDefault)) !=
             hipSuccess) {
         rt_destroy(c);
@@ -120,6 +124,7 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_scene);
     for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
     (void)hipFree(c->d_out);
+    (void)hipFree(c->d_queue);
     (void)hipFree(c->d_rays);
     if (c->h_rays) (void)hipHostFree(c->h_rays);
     for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) {
@@ -159,6 +164,16 @@ static int ensure_out(rt_ctx* c) {
             RT_HIP(hipMemsetAsync(c->d_out, 0, need, c->stream));
             c->out_bytes = need;
         }
+    }
+    // one queue entry (48 B) per local pixel is the worst case (every primary ray hits)
+    const size_t entries = (size_t)rt_padded_tiles(c->H, c->world) * 8u * c->W;
+    if (entries > c->queue_cap) {
+        RT_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_queue);
+        c->d_queue = nullptr;
+        c->queue_cap = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_queue), entries * 3u * sizeof(float4)));
+        c->queue_cap = entries;
     }
     return RT_OK;
 }
@@ -200,9 +215,9 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
         (void)hipFree(c->d_records); (void)hipFree(c->d_scene);
         c->d_records = nullptr; c->d_scene = nullptr;
         c->cap_n = 0;
-        const size_t cap8 = ((size_t)n + 7u) & ~(size_t)7u;
+        const size_t cap16 = ((size_t)n + 15u) & ~(size_t)15u;
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_records), (size_t)n * 32u));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scene), cap8 * 7u * sizeof(float4)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scene), cap16 * 8u * sizeof(float4)));
         c->cap_n = n;
     }
     if (n) {
@@ -210,7 +225,16 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
         RT_HIP(hipStreamSynchronize(c->stream));   // caller may free `records` now (writeBuffer semantics)
     }
     c->n = n;
-    c->n8 = (n + 7u) & ~7u;
+    c->n16 = (n + 15u) & ~15u;
+    {   // scene extent, for the sign-aware filter (rt_kernels.hip: filter_one)
+        double bound = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float* r = records + 8u * (size_t)i;
+            const double len = std::sqrt((double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2]) + std::fabs((double)r[7]);
+            if (!(len <= bound)) bound = len;   // NaN propagates into `bound`
+        }
+        c->scene_bound = (float)bound;
+    }
     c->have_spheres = true;
     c->scene_dirty = true;
     return RT_OK;
@@ -291,30 +315,49 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     if (c->scene_dirty && c->n) {
         RtPrepArgs pa;
         std::memcpy(pa.p, c->params, sizeof pa.p);
-        pa.N = c->n; pa.N8 = c->n8;
+        pa.N = c->n; pa.N16 = c->n16;
         pa.records = c->d_records;
         float4* b = c->d_scene;
-        pa.geo = b; pa.lgt = b + c->n8; pa.cam = b + 2u * c->n8; pa.col = b + 3u * c->n8;
-        pa.geo_f = b + 4u * c->n8; pa.lgt_f = b + 5u * c->n8; pa.cam_f = b + 6u * c->n8;
+        const uint32_t m = c->n16;
+        pa.geo = b; pa.lgt = b + m; pa.cam = b + 2u * m; pa.col = b + 3u * m;
+        pa.geo_f = b + 4u * m; pa.lgt_f = b + 5u * m; pa.cam_f = b + 6u * m;
+        float* w = reinterpret_cast<float*>(b + 7u * m);
+        pa.geo_w = w; pa.lgt_w = w + m; pa.cam_w = w + 2u * m;
         RT_HIP(rt_launch_prep(pa, s));
     }
     c->scene_dirty = (s != c->stream);
-    RT_HIP(hipMemsetAsync(c->d_rays, 0, sizeof(unsigned long long), s));
+    RT_HIP(hipMemsetAsync(c->d_rays, 0, 16, s));
 
     RtFrameArgs fa;
     std::memcpy(fa.p, c->params, sizeof fa.p);
-    fa.W = c->W; fa.H = c->H; fa.N = c->n; fa.N8 = c->n8;
+    fa.W = c->W; fa.H = c->H; fa.N = c->n; fa.N16 = c->n16;
     fa.tile_first = c->rank; fa.tile_step = c->world; fa.n_local_tiles = local_tiles(c);
     {
         const float4* b = c->d_scene;
-        fa.geo = b; fa.lgt = b + c->n8; fa.cam = b + 2u * c->n8; fa.col = b + 3u * c->n8;
-        fa.geo_f = b + 4u * c->n8; fa.lgt_f = b + 5u * c->n8; fa.cam_f = b + 6u * c->n8;
+        const uint32_t m = c->n16;
+        fa.geo = b; fa.lgt = b + m; fa.cam = b + 2u * m; fa.col = b + 3u * m;
+        fa.geo_f = b + 4u * m; fa.lgt_f = b + 5u * m; fa.cam_f = b + 6u * m;
+        const float* w = reinterpret_cast<const float*>(b + 7u * m);
+        fa.geo_w = w; fa.lgt_w = w + m; fa.cam_w = w + 2u * m;
     }
-    if ((size_t)c->n8 * 2u * sizeof(float4) > 160u * 1024u)
-        return fail(RT_ERR_UNSUPPORTED, "rt_render: more than 5120 spheres need chunked LDS staging (not built yet)");
+    if ((size_t)c->n16 * 2u * sizeof(float4) + 8u * 8u * 256u > 160u * 1024u)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render: more than 4608 spheres need chunked LDS staging (not built yet)");
+    {   // sign-aware filter only while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays
+        // below half of the 0.001 a valid hit needs (rt_kernels.hip: filter_one)
+        const float* p = c->params;
+        const double cam = std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
+        const double lgt = std::sqrt((double)p[16] * p[16] + (double)p[17] * p[17] + (double)p[18] * p[18]);
+        double reach = c->scene_bound;
+        if (!(cam <= reach)) reach = cam;
+        if (!(lgt <= reach)) reach = lgt;
+        fa.signed_filter = (reach == reach && 2.0 * reach * 7.3e-7 < 5.0e-4) ? 1u : 0u;
+    }
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
     fa.out = dst;
     fa.rays = c->d_rays;
+    fa.queue = c->d_queue;
+    fa.qctrl = reinterpret_cast<uint32_t*>(c->d_rays) + 2;
+    fa.queue_cap = (uint32_t)c->queue_cap;
     RtLaunchCfg cfg;
     cfg.mode = c->mode;
     cfg.variant = c->variant;

@@ -11,33 +11,39 @@
 //
 // How it is computed is CDNA4-specific (measurements: tools/ubench2.hip, tools/ubench3.hip,
 // numbers in DESIGN.md):
-//   * one pixel per lane, one 8x8 pixel tile per wave64 (= one WGSL workgroup, RK:73), WAVES
-//     tiles side by side per workgroup sharing one LDS copy of the scene;
-//   * sphere records are SoA float4: one ds_read_b128 with a wave-uniform address feeds one
-//     ray-sphere test of the whole wave (an SGPR operand would halve the v_fma_f32 rate);
-//   * only v_fma_f32/v_fmac_f32 issue at 2 cycles per wave on gfx950, v_add/v_mul/v_max/v_cmp
-//     take about 4: the per-sphere filter is written as v_fma_f32 only (10 for a ray with a
-//     per-lane origin, 4 for rays from the camera or the light), plus half a v_max3_f32;
+//   * sphere records are SoA float4 staged in LDS: one ds_read_b128 with a wave-uniform address
+//     feeds one ray-sphere test of the whole wave (an SGPR operand would halve the FMA rate);
+//   * only v_fma_f32 issues at ~2 cycles per wave on gfx950 (v_add/v_mul ~3.5, v_max/v_cmp ~4.5):
+//     the per-sphere filter is written as v_fma_f32 only -- 11 for a ray with a per-lane origin,
+//     5 for rays from the camera or the light -- and leaves a per-lane BIT MASK of the spheres
+//     that may be hit, built in the FMA pipe (clamp turns "positive" into 1.0; Horner sum);
 //   * rays that start at one point for all lanes (primary rays at the camera, shadow rays at
 //     the light, RK:151) use records with `origin - center` and `c` precomputed per frame;
-//   * exactness: the filter decides only "can this sphere have discriminant > 0"; it is
-//     conservative (margin 2^-16, see RT_FILTER_KAPPA), and every sphere it lets through is
-//     re-evaluated with the reference's literal arithmetic, in index order, so nearest-hit
-//     selection, t, normals and colours are the oracle's bits.
+//   * exactness: the filter decides only "can this sphere have discriminant > 0 in front of
+//     the origin"; it is conservative (margin 2^-16), and every sphere it lets through is
+//     re-evaluated later with the reference's literal arithmetic, per lane in index order, so
+//     nearest-hit selection, t, normals and colours are the oracle's bits;
+//   * the candidates of a lane are queued in LDS and evaluated after the sphere loop with all
+//     lanes busy (incoherent rays make almost every 16-sphere batch contain a candidate for
+//     SOME lane; evaluating per batch would serialise the wave on 1-2 active lanes);
+//   * two-kernel pipeline: bounce 0 per pixel (coherent, cheap hoisted forms), then persistent
+//     waves that refill idle lanes from a path queue, so the expensive per-lane-origin trace
+//     runs with full waves.
 #include "rt_device.h"
 
 namespace rtk {
 
-// ---- literal nearest-hit loops (RT_MODE_STRICT; also the definition the filter must match) ----
-// Full form (HK:308-318): per-lane ray origin.  G[s] = {cx, cy, cz, r*r}
-__device__ __forceinline__ void exact_full(const float4 g, int s, v3 o, v3 d, float fa, float ta,
+// ---- literal ray-sphere test (HK:308-318) ------------------------------------------------------------
+// SHORTCUT: b >= 0 makes (-b - sqrt(disc)) <= 0, so t <= 0 fails `t > tMin`; skipping the
+// square root and the division then is exact.  The strict kernel keeps the literal form.
+template <bool SHORTCUT>
+__device__ __forceinline__ void exact_full(v3 center, float r2, int s, v3 o, v3 d, float fa, float ta,
                                            float& nearest, int& idx) {
-    const v3 oc = V(o.x - g.x, o.y - g.y, o.z - g.z);
+    const v3 oc = sub(o, center);
     const float b = 2.0f * dot(d, oc);              // HK:309
-    const float c = dot(oc, oc) - g.w;              // HK:310
+    const float c = dot(oc, oc) - r2;               // HK:310
     const float disc = b * b - fa * c;              // HK:311
-    // b >= 0 makes (-b - sqrt(disc)) <= 0, so t <= 0 fails `t > tMin`: skipping it is exact
-    if (disc > 0.0f && b < 0.0f) {                  // HK:316
+    if (disc > 0.0f && (!SHORTCUT || b < 0.0f)) {   // HK:316
         const float t = (-b - sqrtf(disc)) / ta;    // HK:317
         if (t > 0.001f && t < nearest) {            // HK:318 with tMin/tMax of RK:315
             nearest = t;
@@ -45,12 +51,13 @@ __device__ __forceinline__ void exact_full(const float4 g, int s, v3 o, v3 d, fl
         }
     }
 }
-// Hoisted form: P[s] = {o-c, |o-c|^2 - r^2} for the common origin o.
-__device__ __forceinline__ void exact_hoisted(const float4 g, int s, v3 d, float fa, float ta,
+// Hoisted form: oc = o - center and c = |oc|^2 - r^2 precomputed for the common origin o.
+template <bool SHORTCUT>
+__device__ __forceinline__ void exact_hoisted(v3 oc, float c, int s, v3 d, float fa, float ta,
                                               float& nearest, int& idx) {
-    const float b = 2.0f * dot(d, V(g.x, g.y, g.z));
-    const float disc = b * b - fa * g.w;
-    if (disc > 0.0f && b < 0.0f) {
+    const float b = 2.0f * dot(d, oc);
+    const float disc = b * b - fa * c;
+    if (disc > 0.0f && (!SHORTCUT || b < 0.0f)) {
         const float t = (-b - sqrtf(disc)) / ta;
         if (t > 0.001f && t < nearest) {
             nearest = t;
@@ -59,6 +66,7 @@ __device__ __forceinline__ void exact_hoisted(const float4 g, int s, v3 d, float
     }
 }
 
+// RT_MODE_STRICT: the literal loop over the exact records.
 template <bool FULL>
 __device__ __forceinline__ void trace_literal(const float4* __restrict__ E, uint32_t N, v3 o, v3 d,
                                               float& nearest, int& idx) {
@@ -69,14 +77,15 @@ __device__ __forceinline__ void trace_literal(const float4* __restrict__ E, uint
     idx = -1;
 #pragma unroll 4
     for (uint32_t s = 0; s < N; ++s) {
-        if (FULL) exact_full(E[s], (int)s, o, d, fa, ta, nearest, idx);
-        else      exact_hoisted(E[s], (int)s, d, fa, ta, nearest, idx);
+        const float4 g = E[s];
+        if (FULL) exact_full<false>(V(g.x, g.y, g.z), g.w, (int)s, o, d, fa, ta, nearest, idx);
+        else      exact_hoisted<false>(V(g.x, g.y, g.z), g.w, (int)s, d, fa, ta, nearest, idx);
     }
 }
 
-// ---- filtered nearest-hit loop (RT_MODE_FAST) ---------------------------------------------------
+// ---- RT_MODE_FAST: filtered nearest-hit search ---------------------------------------------------------
 // v_fma_f32 forms (inline asm so that instruction selection is ours: the compiler would turn
-// fma(x,1,y) into v_add_f32 and fma(x,y,0) into v_mul_f32, both half rate on gfx950)
+// fma(x,1,y) into v_add_f32 and fma(x,y,0) into v_mul_f32, both slower on gfx950)
 __device__ __forceinline__ float fma_vvv(float a, float b, float c) {
     float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
 }
@@ -86,107 +95,180 @@ __device__ __forceinline__ float mul_fma(float a, float b) {          // a*b
 __device__ __forceinline__ float sub_fma(float o, float c) {          // o - c
     float d; asm("v_fma_f32 %0, %1, -1.0, %2" : "=v"(d) : "v"(c), "v"(o)); return d;
 }
-__device__ __forceinline__ float sq_minus(float b, float c) {         // b*b - c
-    float d; asm("v_fma_f32 %0, %1, %1, -%2" : "=v"(d) : "v"(b), "v"(c)); return d;
-}
 __device__ __forceinline__ float sq_acc(float x, float c) {           // x*x + c
     float d; asm("v_fma_f32 %0, %1, %1, %2" : "=v"(d) : "v"(x), "v"(c)); return d;
-}
-__device__ __forceinline__ float max3_(float a, float b, float c) {   // no NaN canonicalisation moves
-    float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
 }
 __device__ __forceinline__ float sq_sub(float x, float r) {           // x*x - r
     float d; asm("v_fma_f32 %0, %1, %1, -%2" : "=v"(d) : "v"(x), "v"(r)); return d;
 }
+// clamp(b*b - c) to [0,1]: exactly 1.0 when the 2^80-scaled discriminant is positive (then it
+// is >= 1: b*b and c are either both integers -- |c| >= 2^24 whenever c != 0, because c is
+// the rounded difference of numbers of magnitude 2^80 |oc|^2 --, or c == 0 and b*b < 1 needs
+// |h.oc| < 2^-40 at the same time: a double coincidence of measure zero), else 0.0
+template <bool SGN>
+__device__ __forceinline__ float disc_ind(float b, float c) {
+    float d;
+    if (SGN) asm("v_fma_f32 %0, -%1, |%1|, -%2 clamp" : "=v"(d) : "v"(b), "v"(c));   // -b|b| - c: b*b - c if b < 0
+    else     asm("v_fma_f32 %0, %1, %1, -%2 clamp" : "=v"(d) : "v"(b), "v"(c));      // b*b - c
+    return d;
+}
+__device__ __forceinline__ float shift_in(float code, float bit) {    // 2*code + bit
+    float d; asm("v_fma_f32 %0, %1, 2.0, %2" : "=v"(d) : "v"(code), "v"(bit)); return d;
+}
 
-// Conservative test "can sphere s have discriminant > 0 for this ray".
-// With h = d/|d| the reference's condition b^2 - 4a*c > 0 (HK:311,316) is (h.oc)^2 - c > 0.
-// The filter evaluates that with fused arithmetic, h scaled by (1+kappa) and r^2 by (1+kappa):
-// the value it tests exceeds the real one by >= kappa*(|oc|^2 + r^2)/2 for every sphere whose
-// real discriminant is not clearly negative, while the rounding of the filter (<= 14u) and of
-// the literal evaluation (<= 8u, u = 2^-24, both relative to |oc|^2 + r^2) together stay below
-// 22u = kappa/50.  Spheres with c <= 0 (origin inside or on the sphere) always pass.
-template <bool FULL>
-__device__ __forceinline__ float filter_one(const float4 g, v3 o, v3 h) {
+// Conservative test "can sphere s have discriminant > 0 (and lie in front of the origin)".
+// With h = d/|d| the reference's condition b^2 - 4a*c > 0 (HK:311,316) is (h.oc)^2 - c > 0.  The
+// filter evaluates that with fused arithmetic on records scaled by 2^40, h scaled by (1+kappa)
+// and r^2 by (1+kappa): the value it tests exceeds the real one by >= kappa*(|oc|^2 + r^2)/2
+// (times 2^80) for every sphere whose real discriminant is not clearly negative, while the
+// rounding of the filter (<= 14u) and of the literal evaluation (<= 8u, u = 2^-24, both
+// relative to |oc|^2 + r^2) together stay below 22u = kappa/50.  Spheres with c <= 0 (origin
+// inside or on the sphere) always pass.  SGN additionally rejects spheres behind the origin
+// (b > 0 and c > 0): a valid hit needs t > 0.001, i.e. h.oc < -0.001, and the host enables SGN
+// only when the scene is small enough for the rounding of h.oc (<= 7.3e-7 |oc|) to stay below
+// half of that.
+template <bool FULL, bool SGN>
+__device__ __forceinline__ float filter_one(const float4 g, v3 os, v3 h) {
     if (FULL) {
-        const float ocx = sub_fma(o.x, g.x), ocy = sub_fma(o.y, g.y), ocz = sub_fma(o.z, g.z);
+        const float ocx = sub_fma(os.x, g.x), ocy = sub_fma(os.y, g.y), ocz = sub_fma(os.z, g.z);
         const float b = fma_vvv(h.z, ocz, fma_vvv(h.y, ocy, mul_fma(h.x, ocx)));
         const float c = sq_acc(ocz, sq_acc(ocy, sq_sub(ocx, g.w)));
-        return sq_minus(b, c);
+        return disc_ind<SGN>(b, c);
     } else {
         const float b = fma_vvv(h.z, g.z, fma_vvv(h.y, g.y, mul_fma(h.x, g.x)));
-        return sq_minus(b, g.w);
+        return disc_ind<SGN>(b, g.w);
     }
 }
 
-// F: filter records (LDS), padded to N8 = multiple of 8; X: exact records (global, [N]).
-template <bool FULL>
-__device__ __forceinline__ void trace_filtered(const float4* __restrict__ F, const float4* __restrict__ X,
-                                               uint32_t N8, v3 o, v3 d, float& nearest, int& idx) {
-    const float a = dot(d, d);
-    const float fa = 4.0f * a;
-    const float ta = 2.0f * a;
-    const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_FILTER_KAPPA);
-    const v3 h = V(d.x * inv, d.y * inv, d.z * inv);
-    nearest = 9999.0f;
-    idx = -1;
-    for (uint32_t s = 0; s < N8; s += 8) {
-        float4 g[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) g[k] = F[s + k];
-        float dd[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dd[k] = filter_one<FULL>(g[k], o, h);
-        const float m = max3_(max3_(dd[0], dd[1], dd[2]), max3_(dd[3], dd[4], dd[5]), max3_(dd[6], dd[7], dd[7]));
-        if (m > 0.0f) {
-            // rare: per-lane list of the spheres that passed, visited in index order
-            uint32_t mask = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) mask |= dd[k] > 0.0f ? (1u << k) : 0u;
-            while (mask) {
-                const int si = (int)s + (__ffs((int)mask) - 1);
-                mask &= mask - 1u;
-                const float4 e = X[si];
-                if (FULL) exact_full(e, si, o, d, fa, ta, nearest, idx);
-                else      exact_hoisted(e, si, d, fa, ta, nearest, idx);
-            }
-        }
-    }
-}
-
-// ---- shading of one bounce after the nearest hit is known (RK:128-140) -----------------------
-struct PathState {
-    v3 ro, rd, color;
-    float affect, sum, dist;
+// Per-wave candidate list in LDS: CAP entries per lane, entry-major ([entry][lane]) so that the
+// 64 lanes of a store hit 64 different banks.  Entry = (first sphere of the batch << 16) | 16-bit
+// mask, bit (15-k) = sphere k of the batch.
+template <int CAP>
+struct CandList {
+    uint32_t* slot;   // this lane's column: slot[i * 64]
 };
 
-// ---- kernel: pixel per lane ----------------------------------------------------------------------
+// F: filter records (LDS, [N16]); Wx: exact 4th components ([N16], LDS or global).
+// FULL: F = {center*2^30, r2f*2^60}, Wx = r*r.  Hoisted: F = {oc*2^30, cf*2^60}, Wx = c.
+template <bool FULL, bool SGN, int CAP>
+__device__ __forceinline__ void trace_filtered(const float4* __restrict__ F, const float* __restrict__ Wx,
+                                               uint32_t N16, CandList<CAP> cl, v3 o, v3 d,
+                                               float& nearest, int& idx) {
+    const float a = dot(d, d);           // HK:308
+    const float fa = 4.0f * a;           // the (4*a) of HK:311
+    const float ta = 2.0f * a;           // HK:317
+    const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_FILTER_KAPPA);
+    const v3 h = V(d.x * inv, d.y * inv, d.z * inv);
+    const v3 os = V(o.x * RT_FILTER_SCALE, o.y * RT_FILTER_SCALE, o.z * RT_FILTER_SCALE);   // exact
+    nearest = 9999.0f;                   // RK:172
+    idx = -1;
+    uint32_t cnt = 0;
+
+    // literal evaluation of this lane's queued candidates, in index order
+    auto drain = [&]() {
+        uint32_t i = 0, bits = 0, base = 0;
+        for (;;) {
+            if (bits == 0u && i < cnt) {
+                const uint32_t e = cl.slot[i * 64u];
+                bits = e & 0xFFFFu;
+                base = e >> 16;
+                ++i;
+            }
+            if (__ballot(bits != 0u) == 0ull) break;
+            if (bits != 0u) {
+                const uint32_t lz = (uint32_t)__clz((int)bits);          // highest bit first = lowest index
+                bits &= ~(0x80000000u >> lz);
+                const int si = (int)(base + (lz - 16u));
+                const float4 g = F[si];
+                const float w = Wx[si];
+                const v3 p = V(g.x * RT_FILTER_UNSCALE, g.y * RT_FILTER_UNSCALE, g.z * RT_FILTER_UNSCALE);   // exact
+                if (FULL) exact_full<true>(p, w, si, o, d, fa, ta, nearest, idx);
+                else      exact_hoisted<true>(p, w, si, d, fa, ta, nearest, idx);
+            }
+        }
+        cnt = 0;
+    };
+
+    // software pipeline: the 8 ds_read_b128 of the next half-batch are in flight while the
+    // current one is evaluated (the arrays carry 8 records of slack past N16)
+    float4 g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = F[k];
+    for (uint32_t s = 0; s < N16; s += 16u) {
+        float code = 0.0f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 gn[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gn[k] = F[s + 8u * (half + 1) + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                code = shift_in(code, filter_one<FULL, SGN>(g[k], os, h));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = gn[k];
+        }
+        if (code > 0.0f) {
+            cl.slot[cnt * 64u] = (s << 16) | (uint32_t)code;
+            ++cnt;
+        }
+        if (__ballot(cnt >= (uint32_t)CAP) != 0ull) drain();
+    }
+    drain();
+}
+
+// ---- LDS layout ------------------------------------------------------------------------------------------
+struct SceneLds {
+    const float4 *Gf, *Lf, *Cf;     // filter records (or the exact records in strict mode)
+    const float *Gw, *Lw, *Cw;      // exact 4th components
+};
+
+// ---- kernel: pixel per lane ------------------------------------------------------------------------------
+// One pixel per lane, one 8x8 pixel tile per wave64 (= one WGSL workgroup, RK:73), WAVES tiles
+// side by side per workgroup sharing one LDS copy of the scene.
 // FILTER=false: RT_MODE_STRICT, literal loops over the exact records staged in LDS.
-// FILTER=true : RT_MODE_FAST, filtered loops over the filter records staged in LDS; the exact
-//               records of the few spheres that pass come from global memory (L2-resident).
-// LDS: 3 arrays (geo, light-hoisted, camera-hoisted) x N8 x 16 B when CAM_LDS, else 2.
-template <int WAVES, bool FILTER, bool CAM_LDS>
+// FILTER=true : RT_MODE_FAST, filtered search.
+// FIRST=true  : first stage of the two-kernel pipeline: bounce 0 only (primary ray + its shadow
+//               ray, both hoisted forms, rays coherent inside the tile); pixels whose path ends
+//               here are written, the others are appended to the path queue (one atomicAdd per
+//               wave) for trace_paths.  Stages only the light and camera records.
+// W_LDS       : exact 4th components in LDS too (else read from global when a candidate is evaluated).
+//               In strict mode (no 4th-component arrays) the flag means "camera records in LDS":
+//               false keeps them in global memory so that 4096 spheres still fit.
+template <int WAVES, bool FILTER, bool FIRST, bool SGN, bool W_LDS, int CAP>
 __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
-    const uint32_t N = A.N, N8 = A.N8;
-    float4* sG = lds;
-    float4* sL = lds + N8;
-    float4* sC = lds + 2 * N8;
-    {
-        const float4* srcG = FILTER ? A.geo_f : A.geo;
-        const float4* srcL = FILTER ? A.lgt_f : A.lgt;
-        const float4* srcC = FILTER ? A.cam_f : A.cam;
-        const uint32_t n = FILTER ? N8 : N;
-        for (uint32_t i = threadIdx.x; i < n; i += 64 * WAVES) {
-            sG[i] = srcG[i];
-            sL[i] = srcL[i];
-            if (CAM_LDS) sC[i] = srcC[i];
+    const uint32_t N = A.N, N16 = A.N16;
+    const uint32_t n = FILTER ? N16 : N;
+    // float4 arrays first, then the float arrays, then the candidate lists
+    constexpr bool CAM_LDS = FILTER || W_LDS;
+    float4* sL = lds;
+    float4* sC = lds + n;
+    float4* sG = lds + (CAM_LDS ? 2 : 1) * n;       // unused when FIRST
+    float* wbase = reinterpret_cast<float*>(lds + (FIRST ? 2 : 3) * n);
+    float* sLw = wbase;
+    float* sCw = wbase + n;
+    float* sGw = wbase + 2 * n;
+    uint32_t* lists = reinterpret_cast<uint32_t*>(wbase + ((FILTER && W_LDS) ? (FIRST ? 2 : 3) * n : 0));
+    for (uint32_t i = threadIdx.x; i < n; i += 64 * WAVES) {
+        sL[i] = FILTER ? A.lgt_f[i] : A.lgt[i];
+        if (CAM_LDS) sC[i] = FILTER ? A.cam_f[i] : A.cam[i];
+        if (!FIRST) sG[i] = FILTER ? A.geo_f[i] : A.geo[i];
+        if (FILTER && W_LDS) {
+            sLw[i] = A.lgt_w[i];
+            sCw[i] = A.cam_w[i];
+            if (!FIRST) sGw[i] = A.geo_w[i];
         }
-        __syncthreads();
     }
-    const float4* camRec = CAM_LDS ? sC : (FILTER ? A.cam_f : A.cam);
+    __syncthreads();
+    const float* Lw = (FILTER && W_LDS) ? sLw : A.lgt_w;
+    const float* Cw = (FILTER && W_LDS) ? sCw : A.cam_w;
+    const float* Gw = (FILTER && W_LDS) ? sGw : A.geo_w;
+    const float4* camE = CAM_LDS ? sC : A.cam;      // strict mode only
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    CandList<CAP> cl;
+    cl.slot = lists + wave * (uint32_t)(CAP * 64) + lane;
+
     const uint32_t x = blockIdx.x * (8u * WAVES) + wave * 8u + (lane & 7u);
     const uint32_t row = lane >> 3;
     const uint32_t y = (A.tile_first + blockIdx.y * A.tile_step) * 8u + row;
@@ -201,14 +283,16 @@ __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) 
     v3 color = V(1.0f, 1.0f, 1.0f);
     v3 ro = sc.cameraPos, rd = dir0;
     float affect = 1.0f, sum = 0.0f;
-    for (uint32_t bounce = 0; bounce < sc.bounces; ++bounce) {
+    bool alive = true;
+    const uint32_t nb = FIRST ? (sc.bounces ? 1u : 0u) : sc.bounces;
+    for (uint32_t bounce = 0; bounce < nb; ++bounce) {
         float t; int idx;
         if (FILTER) {
-            if (bounce == 0) trace_filtered<false>(camRec, A.cam, N8, ro, rd, t, idx);
-            else             trace_filtered<true>(sG, A.geo, N8, ro, rd, t, idx);
+            if (FIRST || bounce == 0) trace_filtered<false, SGN, CAP>(sC, Cw, N16, cl, ro, rd, t, idx);
+            else                      trace_filtered<true, SGN, CAP>(sG, Gw, N16, cl, ro, rd, t, idx);
         } else {
-            if (bounce == 0) trace_literal<false>(camRec, N, ro, rd, t, idx);
-            else             trace_literal<true>(sG, N, ro, rd, t, idx);
+            if (FIRST || bounce == 0) trace_literal<false>(camE, N, ro, rd, t, idx);
+            else                      trace_literal<true>(sG, N, ro, rd, t, idx);
         }
         ++nrays;
         const bool hit = idx >= 0;
@@ -217,10 +301,11 @@ __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) 
         if (!hit) {                                              // RK:122-126
             const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
             color = divs(add(scale(sum, color), scale(affect, sky)), next);
+            alive = false;
             break;
         }
         const float4 g = A.geo[idx];
-        const float4 cl = A.col[idx];
+        const float4 cl4 = A.col[idx];
         const v3 pos = add(ro, scale(t, rd));                    // HK:319 == RK:129
         const v3 normal = normalize(sub(pos, V(g.x, g.y, g.z))); // HK:320
         ro = pos;
@@ -230,30 +315,162 @@ __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) 
         const v3 sdir = normalize(sub(ro, sc.lightPos));         // RK:147
         const float distance = length(sdir);                     // RK:148
         float st; int sidx;
-        if (FILTER) trace_filtered<false>(sL, A.lgt, N8, sc.lightPos, sdir, st, sidx);
+        if (FILTER) trace_filtered<false, SGN, CAP>(sL, Lw, N16, cl, sc.lightPos, sdir, st, sidx);
         else        trace_literal<false>(sL, N, sc.lightPos, sdir, st, sidx);
         ++nrays;
         const float intensity = light_term(sc, ro, normal, sdir, distance, sidx >= 0, st);
-        const v3 blended = scale(intensity, V(cl.x, cl.y, cl.z)); // RK:133-135, diffuse.w == 1
+        const v3 blended = scale(intensity, V(cl4.x, cl4.y, cl4.z)); // RK:133-135, diffuse.w == 1
         color = divs(add(scale(sum, color), scale(affect, blended)), next); // RK:136
         affect = affect / 2.0f;                                  // RK:139
         sum = next;                                              // RK:140
     }
 
-    const uint32_t packed = compose_pixel(A, sc, dir0, color, dist);   // RK:91-98
-    const size_t orow = (size_t)blockIdx.y * 8u + row;
-    reinterpret_cast<uint32_t*>(A.out)[orow * A.W + x] = packed;
+    const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;           // index in the compact tile buffer
+    bool cont = false;
+    if (FIRST) {
+        // the path goes on (bounce 1..) in trace_paths: append {ro, pixel}, {rd, dist}, {color}
+        cont = alive && sc.bounces > 1u;
+        const uint64_t m = __ballot(cont);
+        if (m) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&A.qctrl[0], (uint32_t)__popcll(m));
+            base = __shfl(base, (int)leader, 64);
+            if (cont) {
+                float4* q = A.queue + 3u * (size_t)(base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+                q[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(opix));
+                q[1] = make_float4(rd.x, rd.y, rd.z, dist);
+                q[2] = make_float4(color.x, color.y, color.z, 0.0f);
+            }
+        }
+    }
+    if (!cont) reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, dir0, color, dist);   // RK:91-98
+    count_rays(A.rays, nrays);
+}
+
+// ---- kernel: second stage of the pipeline, bounces 1.. with path regeneration -------------------
+// Persistent waves: every lane carries one path; a lane whose path ends (miss RK:122-126, or
+// the bounce limit) takes the next entry of the path queue, so the per-lane-origin trace (the
+// expensive one, 12 FMAs per sphere) runs with all 64 lanes busy while the queue lasts.
+// Entries are popped in chunks of 64 with one atomicAdd per chunk; neighbouring entries come
+// from the same 8x8 tile of the first stage.  There is no inter-workgroup dependency: a
+// workgroup that finds the queue empty exits.
+template <int WAVES, bool SGN, bool W_LDS, int CAP>
+__global__ __launch_bounds__(64 * WAVES) void trace_paths(const RtFrameArgs A) {
+    extern __shared__ float4 lds[];
+    const uint32_t N16 = A.N16;
+    float4* sG = lds;
+    float4* sL = lds + N16;
+    float* sGw = reinterpret_cast<float*>(lds + 2 * N16);
+    float* sLw = sGw + N16;
+    uint32_t* lists = reinterpret_cast<uint32_t*>(sGw + (W_LDS ? 2 * N16 : 0));
+    for (uint32_t i = threadIdx.x; i < N16; i += 64 * WAVES) {
+        sG[i] = A.geo_f[i];
+        sL[i] = A.lgt_f[i];
+        if (W_LDS) { sGw[i] = A.geo_w[i]; sLw[i] = A.lgt_w[i]; }
+    }
+    __syncthreads();
+    const float* Gw = W_LDS ? sGw : A.geo_w;
+    const float* Lw = W_LDS ? sLw : A.lgt_w;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    CandList<CAP> cl;
+    cl.slot = lists + wave * (uint32_t)(CAP * 64) + lane;
+
+    const Scene sc = unpack_scene(A);
+    const uint32_t total = A.qctrl[0];           // written by the first stage (previous kernel)
+    uint32_t cur = 0, end = 0;                    // wave-uniform chunk cursor
+    bool exhausted = false;
+
+    bool active = false;
+    uint32_t opix = 0, bounce = 0, nrays = 0;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(0, 0, 0);
+    float dist = 0.0f, affect = 0.0f, sum = 0.0f;
+
+    for (;;) {
+        // ---- refill idle lanes from the queue ----
+        uint64_t idle = __ballot(!active);
+        while (idle && !exhausted) {
+            if (cur == end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&A.qctrl[1], 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= total) { exhausted = true; break; }
+                cur = base;
+                end = min(base + 64u, total);
+            }
+            const uint32_t nidle = (uint32_t)__popcll(idle);
+            const uint32_t take = min(nidle, end - cur);
+            const uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && r < take) {
+                const float4* q = A.queue + 3u * (size_t)(cur + r);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                ro = V(q0.x, q0.y, q0.z); opix = __float_as_uint(q0.w);
+                rd = V(q1.x, q1.y, q1.z); dist = q1.w;
+                color = V(q2.x, q2.y, q2.z);
+                // state after bounce 0: affectFactor 1 -> 1/2, sumFactor 0 -> 1 (RK:139-140)
+                affect = 0.5f; sum = 1.0f; bounce = 1u;
+                active = true;
+            }
+            cur += take;
+            idle = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+
+        bool finished = false;
+        if (active) {
+            // ---- RK:114: trace the reflection ray (per-lane origin) ----
+            float t; int idx;
+            trace_filtered<true, SGN, CAP>(sG, Gw, N16, cl, ro, rd, t, idx);
+            ++nrays;
+            const float next = affect + sum;                         // RK:120
+            if (idx < 0) {                                           // RK:122-126
+                const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
+                color = divs(add(scale(sum, color), scale(affect, sky)), next);
+                finished = true;
+            } else {
+                const float4 g = A.geo[idx];
+                const float4 cl4 = A.col[idx];
+                const v3 pos = add(ro, scale(t, rd));                    // RK:129
+                const v3 normal = normalize(sub(pos, V(g.x, g.y, g.z))); // HK:320
+                ro = pos;
+                rd = normalize(reflect(rd, normal));                     // RK:130
+                // ---- RK:146-153: shadow ray from the light (hoisted form) ----
+                const v3 sdir = normalize(sub(ro, sc.lightPos));
+                const float distance = length(sdir);
+                float st; int sidx;
+                trace_filtered<false, SGN, CAP>(sL, Lw, N16, cl, sc.lightPos, sdir, st, sidx);
+                ++nrays;
+                const float intensity = light_term(sc, ro, normal, sdir, distance, sidx >= 0, st);
+                const v3 blended = scale(intensity, V(cl4.x, cl4.y, cl4.z));
+                color = divs(add(scale(sum, color), scale(affect, blended)), next);   // RK:136
+                affect = affect / 2.0f;                                  // RK:139
+                sum = next;                                              // RK:140
+                ++bounce;
+                finished = bounce >= sc.bounces;                         // RK:113
+            }
+        }
+        if (finished) {
+            // RK:91-98: the primary direction is a function of the pixel alone; recompute it
+            const uint32_t orow = opix / A.W, x = opix - orow * A.W;
+            const uint32_t y = (A.tile_first + (orow >> 3) * A.tile_step) * 8u + (orow & 7u);
+            const v3 dir0 = primary_dir(A, sc, x, y);
+            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, dir0, color, dist);
+            active = false;
+        }
+    }
     count_rays(A.rays, nrays);
 }
 
 // ---- per-frame scene preparation ---------------------------------------------------------------
 __global__ void prep_spheres(const RtPrepArgs A) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.N8) return;
+    if (i >= A.N16) return;
     if (i >= A.N) {   // padding records: can never pass the filter
         A.geo_f[i] = make_float4(0.0f, 0.0f, 0.0f, -INFINITY);
         A.lgt_f[i] = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
         A.cam_f[i] = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+        A.geo_w[i] = 0.0f; A.lgt_w[i] = 0.0f; A.cam_w[i] = 0.0f;
         return;
     }
     const float* r = A.records + 8u * i;
@@ -267,42 +484,121 @@ __global__ void prep_spheres(const RtPrepArgs A) {
     A.lgt[i] = make_float4(lo.x, lo.y, lo.z, ll - r2);                  // HK:310
     A.cam[i] = make_float4(co.x, co.y, co.z, cc - r2);
     A.col[i] = make_float4(r[4], r[5], r[6], 0.0f);
+    A.geo_w[i] = r2; A.lgt_w[i] = ll - r2; A.cam_w[i] = cc - r2;
+    const float S = RT_FILTER_SCALE, S2 = RT_FILTER_SCALE2;
     const float r2f = r2 * (1.0f + RT_FILTER_KAPPA);
-    A.geo_f[i] = make_float4(c.x, c.y, c.z, r2f);
-    A.lgt_f[i] = make_float4(lo.x, lo.y, lo.z, ll - r2f);
-    A.cam_f[i] = make_float4(co.x, co.y, co.z, cc - r2f);
+    A.geo_f[i] = make_float4(c.x * S, c.y * S, c.z * S, r2f * S2);
+    A.lgt_f[i] = make_float4(lo.x * S, lo.y * S, lo.z * S, (ll - r2f) * S2);
+    A.cam_f[i] = make_float4(co.x * S, co.y * S, co.z * S, (cc - r2f) * S2);
 }
 
-template <int WAVES, bool FILTER, bool CAM_LDS>
+// ---- launch ------------------------------------------------------------------------------------------------
+template <typename K>
+hipError_t set_lds(K k, size_t lds) {
+    if (lds > 48u * 1024u)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return hipSuccess;
+}
+
+constexpr size_t kLdsCap = 160u * 1024u;
+
+// bytes of LDS a pixel-kernel workgroup needs
+template <int WAVES, bool FILTER, bool FIRST, bool W_LDS, int CAP>
+size_t lds_pixels(const RtFrameArgs& a) {
+    const size_t n = FILTER ? a.N16 : a.N;
+    const size_t arrays = FIRST ? 2 : ((FILTER || W_LDS) ? 3 : 2);
+    return n * arrays * 16u + ((FILTER && W_LDS) ? n * arrays * 4u : 0u) + (FILTER ? (size_t)WAVES * CAP * 256u : 0u);
+}
+
+template <int WAVES, bool FILTER, bool FIRST, bool SGN, bool W_LDS, int CAP>
 hipError_t launch_pixels(const RtFrameArgs& a, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
-    const size_t lds = (size_t)a.N8 * (CAM_LDS ? 3u : 2u) * sizeof(float4);
-    auto k = trace_pixels<WAVES, FILTER, CAM_LDS>;
-    if (lds > 48u * 1024u) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    const size_t lds = lds_pixels<WAVES, FILTER, FIRST, W_LDS, CAP>(a);
+    if (lds > kLdsCap) return hipErrorInvalidValue;
+    auto k = trace_pixels<WAVES, FILTER, FIRST, SGN, W_LDS, CAP>;
+    hipError_t e = set_lds(k, lds);
+    if (e != hipSuccess) return e;
     dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
     hipLaunchKernelGGL(k, grid, dim3(64 * WAVES), lds, s, a);
     return hipGetLastError();
 }
 
-template <bool FILTER>
-hipError_t launch_mode(const RtFrameArgs& a, int variant, hipStream_t s) {
-    const size_t rec = (size_t)a.N8 * sizeof(float4);
-    const size_t cap = 160u * 1024u;
-    if (2 * rec > cap) return hipErrorInvalidValue;   // > 5120 spheres: not built yet (chunked staging)
-    const bool cam = 3 * rec <= cap;
+template <int WAVES, bool W_LDS, int CAP>
+size_t lds_paths(const RtFrameArgs& a) {
+    return (size_t)a.N16 * 32u + (W_LDS ? (size_t)a.N16 * 8u : 0u) + (size_t)WAVES * CAP * 256u;
+}
+
+template <int WAVES, bool SGN, bool W_LDS, int CAP>
+hipError_t launch_paths(const RtFrameArgs& a, hipStream_t s) {
+    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    const size_t lds = lds_paths<WAVES, W_LDS, CAP>(a);
+    if (lds > kLdsCap) return hipErrorInvalidValue;
+    auto k = trace_paths<WAVES, SGN, W_LDS, CAP>;
+    hipError_t e = set_lds(k, lds);
+    if (e != hipSuccess) return e;
+    // persistent grid: enough workgroups to fill 256 CUs at the residency LDS allows;
+    // surplus workgroups find the queue empty and exit
+    const uint32_t per_cu = (uint32_t)min((size_t)(32 / WAVES), kLdsCap / lds);
+    const uint32_t pixels = a.n_local_tiles * 8u * a.W;
+    uint32_t blocks = 256u * (per_cu ? per_cu : 1u);
+    const uint32_t need = (pixels + 64u * WAVES - 1u) / (64u * WAVES);
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
+    return hipGetLastError();
+}
+
+// RT_MODE_STRICT: one literal kernel, exact records in LDS
+hipError_t launch_strict(const RtFrameArgs& a, hipStream_t s) {
+    const size_t bytes = (size_t)a.N * 48u;
+    if (bytes <= 56u * 1024u) return launch_pixels<8, false, false, false, true, 1>(a, s);
+    if (bytes <= kLdsCap)     return launch_pixels<16, false, false, false, true, 1>(a, s);
+    if ((size_t)a.N * 32u <= kLdsCap) return launch_pixels<16, false, false, false, false, 1>(a, s);
+    return hipErrorInvalidValue;
+}
+
+template <bool SGN>
+hipError_t launch_fast(const RtFrameArgs& a, int variant, hipStream_t s) {
+    const size_t rec = (size_t)a.N16 * 16u;
+    const bool small = 3 * rec + 3 * (rec / 4) + 8u * 16u * 256u <= 80u * 1024u;      // N <= ~800: 2 workgroups of 8 waves per CU
+    const bool pipeline = a.queue && a.qctrl && a.N >= 128u;
     switch (variant) {
-        case 0:
-        case 1:   // 8 waves (64x8 px) per workgroup; 16 when the scene takes most of a CU's LDS
-            if (3 * rec <= 80u * 1024u) return launch_pixels<8, FILTER, true>(a, s);
-            return cam ? launch_pixels<16, FILTER, true>(a, s) : launch_pixels<16, FILTER, false>(a, s);
-        case 2:
-            return cam ? launch_pixels<4, FILTER, true>(a, s) : launch_pixels<16, FILTER, false>(a, s);
-        case 3:
-            return cam ? launch_pixels<16, FILTER, true>(a, s) : launch_pixels<16, FILTER, false>(a, s);
+        case 0:   // default: two-kernel pipeline for scenes where the sphere loop dominates,
+                  // single kernel for small scenes (the queue round trip costs more than it saves)
+            if (pipeline) {
+                hipError_t e;
+                if (2 * rec + rec / 2 + 8u * 16u * 256u <= 80u * 1024u) {        // N <= ~1200
+                    e = launch_pixels<8, true, true, SGN, true, 16>(a, s);
+                    if (e != hipSuccess) return e;
+                    return launch_paths<8, SGN, true, 16>(a, s);
+                }
+                if (lds_paths<8, true, 16>(a) <= kLdsCap) {                      // N <= ~3600
+                    e = launch_pixels<8, true, true, SGN, true, 16>(a, s);
+                    if (e != hipSuccess) return e;
+                    return launch_paths<8, SGN, true, 16>(a, s);
+                }
+                e = launch_pixels<8, true, true, SGN, false, 8>(a, s);           // N <= 5120: w from global
+                if (e != hipSuccess) return e;
+                return launch_paths<8, SGN, false, 8>(a, s);
+            }
+            [[fallthrough]];
+        case 1:   // single kernel
+            if (small) return launch_pixels<8, true, false, SGN, true, 16>(a, s);
+            if (lds_pixels<8, true, false, true, 16>(a) <= kLdsCap) return launch_pixels<8, true, false, SGN, true, 16>(a, s);
+            return hipErrorInvalidValue;   // > ~2700 spheres need the pipeline
+        case 2:   // pipeline, 4-wave workgroups in the path stage
+            if (a.queue && a.qctrl && lds_paths<4, true, 16>(a) <= kLdsCap) {
+                hipError_t e = launch_pixels<8, true, true, SGN, true, 16>(a, s);
+                if (e != hipSuccess) return e;
+                return launch_paths<4, SGN, true, 16>(a, s);
+            }
+            return hipErrorInvalidValue;
+        case 3:   // pipeline forced (also for small scenes)
+            if (a.queue && a.qctrl && lds_paths<8, true, 16>(a) <= kLdsCap) {
+                hipError_t e = launch_pixels<8, true, true, SGN, true, 16>(a, s);
+                if (e != hipSuccess) return e;
+                return launch_paths<8, SGN, true, 16>(a, s);
+            }
+            return hipErrorInvalidValue;
         default:
             return hipErrorInvalidValue;
     }
@@ -311,11 +607,12 @@ hipError_t launch_mode(const RtFrameArgs& a, int variant, hipStream_t s) {
 }  // namespace rtk
 
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s) {
-    return cfg.mode == 1 ? rtk::launch_mode<false>(a, cfg.variant, s) : rtk::launch_mode<true>(a, cfg.variant, s);
+    if (cfg.mode == 1) return rtk::launch_strict(a, s);
+    return a.signed_filter ? rtk::launch_fast<true>(a, cfg.variant, s) : rtk::launch_fast<false>(a, cfg.variant, s);
 }
 
 hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s) {
-    if (a.N8 == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtk::prep_spheres, dim3((a.N8 + 255u) / 256u), dim3(256), 0, s, a);
+    if (a.N16 == 0) return hipSuccess;
+    hipLaunchKernelGGL(rtk::prep_spheres, dim3((a.N16 + 255u) / 256u), dim3(256), 0, s, a);
     return hipGetLastError();
 }

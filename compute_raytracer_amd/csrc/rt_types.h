@@ -5,36 +5,54 @@
 
 // Relative safety margin of the conservative discriminant filter (see rt_kernels.hip).
 #define RT_FILTER_KAPPA 1.52587890625e-05f   // 2^-16
+// Filter records hold positions scaled by 2^40 (exact: a power of two) so that the filter's
+// discriminant is scaled by 2^80: whenever it is positive it is >= 1 (it is a difference of
+// numbers whose granularity exceeds 1, see rt_kernels.hip), and the `clamp` output modifier of
+// the v_fma_f32 that forms it turns "positive" into exactly 1.0 at no extra cost.
+#define RT_FILTER_SCALE 1099511627776.0f                 // 2^40
+#define RT_FILTER_SCALE2 1208925819614629174706176.0f    // 2^80
+#define RT_FILTER_UNSCALE 9.094947017729282379150390625e-13f   // 2^-40
 
 // One frame's launch arguments (kernarg segment -> SGPRs; everything here is wave-uniform).
 struct RtFrameArgs {
     float p[24];               // SceneParameters as RR:157-165 packs them
     uint32_t W, H, N;          // target size, sphere count
-    uint32_t N8;               // N rounded up to a multiple of 8 (filter arrays are padded to it)
+    uint32_t N16;              // N rounded up to a multiple of 16 (filter arrays are padded to it)
     uint32_t tile_first;       // first 8-row tile of this rank
     uint32_t tile_step;        // world size (tile stride)
     uint32_t n_local_tiles;    // tiles this launch renders
+    uint32_t signed_filter;    // 1: the scene is small enough for the sign-aware filter
     // exact records, [N]: the values the reference arithmetic consumes
     const float4* geo;         // {cx, cy, cz, radius*radius}
     const float4* lgt;         // {L-c (xyz), dot(L-c,L-c) - r*r}   ray origin = light  (shadow rays)
     const float4* cam;         // same for ray origin = camera       (primary rays)
     const float4* col;         // {r, g, b, 0}
-    // filter records, [N8]: inflated copies for the conservative discriminant test
-    const float4* geo_f;       // {cx, cy, cz, r*r*(1+kappa)}            pad: w = -inf
-    const float4* lgt_f;       // {L-c (xyz), |L-c|^2 - r*r*(1+kappa)}   pad: w = +inf
+    // filter records, [N16]: scaled, inflated copies for the conservative discriminant test
+    const float4* geo_f;       // {c * 2^40, r*r*(1+kappa) * 2^80}                pad: w = -inf
+    const float4* lgt_f;       // {(L-c) * 2^40, (|L-c|^2 - r*r*(1+kappa)) * 2^80}  pad: w = +inf
     const float4* cam_f;       // same for the camera
+    // exact 4th components next to the filter records, [N16] (xyz is recovered exactly as *2^-40)
+    const float* geo_w;        // r*r
+    const float* lgt_w;        // |L-c|^2 - r*r
+    const float* cam_w;
     const uint8_t* face[6];    // cube faces, rgba8unorm
     uint32_t fw[6], fh[6];
     uint8_t* out;              // compact tile buffer [n_local_tiles*8][W][4]
     unsigned long long* rays;  // scene-traversal counter (one atomicAdd per wave)
+    // path queue between the first-bounce kernel and the path kernel (two-kernel pipeline):
+    // 3 float4 per surviving path {ro.xyz, pixel index}, {rd.xyz, dist}, {color.rgb, 0}
+    float4* queue;             // [queue_cap][3]
+    uint32_t* qctrl;           // [0] entries appended by the first-bounce kernel, [1] pop cursor
+    uint32_t queue_cap;
 };
 
 struct RtPrepArgs {
     float p[24];
-    uint32_t N, N8;
+    uint32_t N, N16;
     const float* records;      // [N][8] {cx,cy,cz,_, r,g,b, radius}
     float4 *geo, *lgt, *cam, *col;
     float4 *geo_f, *lgt_f, *cam_f;
+    float *geo_w, *lgt_w, *cam_w;
 };
 
 struct RtLaunchCfg {
