@@ -57,7 +57,7 @@ struct rt_ctx {
     uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
     uint8_t* d_out = nullptr;
     size_t out_bytes = 0;
-    unsigned long long* d_rays = nullptr;  // 16-byte control block: rays (u64), queue count, queue head
+    unsigned long long* d_rays = nullptr;  // 32-byte control block: rays (u64), queue count, queue head, tile-pair cursor
     float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
     size_t queue_cap = 0;                  // entries
     unsigned long long* h_rays = nullptr;  // pinned
@@ -103,7 +103,7 @@ int rt_create(int device, rt_ctx** out) {
         err = hipEventCreate(&c->ev_k1[i]);
     }
     if (err != hipSuccess ||
-        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), 16)) != hipSuccess ||
+        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), 32)) != hipSuccess ||
         (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), sizeof(unsigned long long), hipHostMallocDefault)) !=
             hipSuccess) {
         rt_destroy(c);
@@ -326,7 +326,7 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         RT_HIP(rt_launch_prep(pa, s));
     }
     c->scene_dirty = (s != c->stream);
-    RT_HIP(hipMemsetAsync(c->d_rays, 0, 16, s));
+    RT_HIP(hipMemsetAsync(c->d_rays, 0, 32, s));
 
     RtFrameArgs fa;
     std::memcpy(fa.p, c->params, sizeof fa.p);

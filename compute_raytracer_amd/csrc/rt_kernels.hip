@@ -127,15 +127,40 @@ __device__ __forceinline__ float shift_in(float code, float bit) {    // 2*code 
 // (b > 0 and c > 0): a valid hit needs t > 0.001, i.e. h.oc < -0.001, and the host enables SGN
 // only when the scene is small enough for the rounding of h.oc (<= 7.3e-7 |oc|) to stay below
 // half of that.
+//
+// Per-lane origin (FULL): the expanded form saves the three `o - c` subtractions.  With the
+// per-ray scalars p = h.o, q = |o|^2 (1-eps), m = -2 o and the per-sphere k = |c|^2 (1-eps) - r^2(1+kappa)
+//     b = p - h.c                      3 FMAs
+//     cp = k + m.c                     3 FMAs      (c = cp + q)
+//     e = b*b - q,  dd = e - cp        2 FMAs      (the last one clamps)
+// Expanding |o-c|^2 costs cancellation error <= 48u (|o|^2 + |c|^2); eps = 2^-17 = 128u shifts the
+// tested value up by eps (|o|^2 + |c|^2), which covers it; the kappa terms cover the rest as above.
+struct RayF {     // per-ray constants of the filter (2^40-scaled where a length)
+    v3 h;         // d/|d| * (1+kappa)
+    v3 m;         // -2 * o * 2^40        (FULL)
+    float p, q;   // h.o * 2^40,  |o|^2 (1-eps) * 2^80   (FULL)
+};
+__device__ __forceinline__ float fnma_vvv(float a, float b, float c) {   // c - a*b
+    float d; asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+template <bool SGN>
+__device__ __forceinline__ float sq_signed_minus(float b, float q) {     // b*b - q  (SGN: -b|b| - q)
+    float d;
+    if (SGN) asm("v_fma_f32 %0, -%1, |%1|, -%2" : "=v"(d) : "v"(b), "v"(q));
+    else     asm("v_fma_f32 %0, %1, %1, -%2" : "=v"(d) : "v"(b), "v"(q));
+    return d;
+}
+__device__ __forceinline__ float sub_clamp(float e, float c) {          // clamp(e - c)
+    float d; asm("v_fma_f32 %0, %1, -1.0, %2 clamp" : "=v"(d) : "v"(c), "v"(e)); return d;
+}
 template <bool FULL, bool SGN>
-__device__ __forceinline__ float filter_one(const float4 g, v3 os, v3 h) {
+__device__ __forceinline__ float filter_one(const float4 g, const RayF& r) {
     if (FULL) {
-        const float ocx = sub_fma(os.x, g.x), ocy = sub_fma(os.y, g.y), ocz = sub_fma(os.z, g.z);
-        const float b = fma_vvv(h.z, ocz, fma_vvv(h.y, ocy, mul_fma(h.x, ocx)));
-        const float c = sq_acc(ocz, sq_acc(ocy, sq_sub(ocx, g.w)));
-        return disc_ind<SGN>(b, c);
+        const float b = fnma_vvv(r.h.z, g.z, fnma_vvv(r.h.y, g.y, fnma_vvv(r.h.x, g.x, r.p)));
+        const float cp = fma_vvv(r.m.z, g.z, fma_vvv(r.m.y, g.y, fma_vvv(r.m.x, g.x, g.w)));
+        return sub_clamp(sq_signed_minus<SGN>(b, r.q), cp);
     } else {
-        const float b = fma_vvv(h.z, g.z, fma_vvv(h.y, g.y, mul_fma(h.x, g.x)));
+        const float b = fma_vvv(r.h.z, g.z, fma_vvv(r.h.y, g.y, mul_fma(r.h.x, g.x)));
         return disc_ind<SGN>(b, g.w);
     }
 }
@@ -158,8 +183,14 @@ __device__ __forceinline__ void trace_filtered(const float4* __restrict__ F, con
     const float fa = 4.0f * a;           // the (4*a) of HK:311
     const float ta = 2.0f * a;           // HK:317
     const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_FILTER_KAPPA);
-    const v3 h = V(d.x * inv, d.y * inv, d.z * inv);
-    const v3 os = V(o.x * RT_FILTER_SCALE, o.y * RT_FILTER_SCALE, o.z * RT_FILTER_SCALE);   // exact
+    RayF rf;
+    rf.h = V(d.x * inv, d.y * inv, d.z * inv);
+    {
+        const v3 os = V(o.x * RT_FILTER_SCALE, o.y * RT_FILTER_SCALE, o.z * RT_FILTER_SCALE);   // exact
+        rf.m = V(-2.0f * os.x, -2.0f * os.y, -2.0f * os.z);
+        rf.p = dot(rf.h, os);
+        rf.q = dot(os, os) * (1.0f - RT_FILTER_EPS);
+    }
     nearest = 9999.0f;                   // RK:172
     idx = -1;
     uint32_t cnt = 0;
@@ -203,7 +234,7 @@ __device__ __forceinline__ void trace_filtered(const float4* __restrict__ F, con
             for (int k = 0; k < 8; ++k) gn[k] = F[s + 8u * (half + 1) + k];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                code = shift_in(code, filter_one<FULL, SGN>(g[k], os, h));
+                code = shift_in(code, filter_one<FULL, SGN>(g[k], rf));
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] = gn[k];
         }
@@ -214,6 +245,85 @@ __device__ __forceinline__ void trace_filtered(const float4* __restrict__ F, con
         if (__ballot(cnt >= (uint32_t)CAP) != 0ull) drain();
     }
     drain();
+}
+
+// Two rays per lane that share one origin (two primary rays, or two shadow rays): the hoisted
+// filter needs only 6 FMAs per ray and sphere, less than the 16 cycles the LDS takes to deliver
+// one record to four SIMDs; evaluating two rays per record read makes the loop VALU-bound.
+template <bool SGN, int CAP>
+__device__ __forceinline__ void trace_hoisted_pair(const float4* __restrict__ F, const float* __restrict__ Wx,
+                                                   uint32_t N16, uint32_t* slot0, uint32_t* slot1,
+                                                   v3 d0, v3 d1, bool act0, bool act1,
+                                                   float& near0, int& idx0, float& near1, int& idx1) {
+    const float a0 = dot(d0, d0), a1 = dot(d1, d1);                    // HK:308
+    const float fa0 = 4.0f * a0, fa1 = 4.0f * a1;
+    const float ta0 = 2.0f * a0, ta1 = 2.0f * a1;
+    const float inv0 = __builtin_amdgcn_rsqf(a0) * (1.0f + RT_FILTER_KAPPA);
+    const float inv1 = __builtin_amdgcn_rsqf(a1) * (1.0f + RT_FILTER_KAPPA);
+    RayF r0, r1;
+    r0.h = V(d0.x * inv0, d0.y * inv0, d0.z * inv0);
+    r1.h = V(d1.x * inv1, d1.y * inv1, d1.z * inv1);
+    near0 = near1 = 9999.0f;                                           // RK:172
+    idx0 = idx1 = -1;
+    uint32_t cnt0 = 0, cnt1 = 0;
+
+    auto drain = [&](uint32_t* slot, uint32_t& cnt, v3 d, float fa, float ta, float& nearest, int& idx) {
+        uint32_t i = 0, bits = 0, base = 0;
+        for (;;) {
+            if (bits == 0u && i < cnt) {
+                const uint32_t e = slot[i * 64u];
+                bits = e & 0xFFFFu;
+                base = e >> 16;
+                ++i;
+            }
+            if (__ballot(bits != 0u) == 0ull) break;
+            if (bits != 0u) {
+                const uint32_t lz = (uint32_t)__clz((int)bits);
+                bits &= ~(0x80000000u >> lz);
+                const int si = (int)(base + (lz - 16u));
+                const float4 g = F[si];
+                const float w = Wx[si];
+                const v3 p = V(g.x * RT_FILTER_UNSCALE, g.y * RT_FILTER_UNSCALE, g.z * RT_FILTER_UNSCALE);   // exact
+                exact_hoisted<true>(p, w, si, d, fa, ta, nearest, idx);
+            }
+        }
+        cnt = 0;
+    };
+
+    // quarter-batches of 4 records keep the register footprint of two rays per lane at 128
+    float4 g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = F[k];
+    for (uint32_t s = 0; s < N16; s += 16u) {
+        float code0 = 0.0f, code1 = 0.0f;
+#pragma unroll
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            float4 gn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gn[k] = F[s + 4u * (quarter + 1) + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                code0 = shift_in(code0, filter_one<false, SGN>(g[k], r0));
+                code1 = shift_in(code1, filter_one<false, SGN>(g[k], r1));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = gn[k];
+        }
+        if (act0 && code0 > 0.0f) {
+            slot0[cnt0 * 64u] = (s << 16) | (uint32_t)code0;
+            ++cnt0;
+        }
+        if (act1 && code1 > 0.0f) {
+            slot1[cnt1 * 64u] = (s << 16) | (uint32_t)code1;
+            ++cnt1;
+        }
+        if (__ballot(cnt0 >= (uint32_t)CAP || cnt1 >= (uint32_t)CAP) != 0ull) {
+            drain(slot0, cnt0, d0, fa0, ta0, near0, idx0);
+            drain(slot1, cnt1, d1, fa1, ta1, near1, idx1);
+        }
+    }
+    drain(slot0, cnt0, d0, fa0, ta0, near0, idx0);
+    drain(slot1, cnt1, d1, fa1, ta1, near1, idx1);
 }
 
 // ---- LDS layout ------------------------------------------------------------------------------------------
@@ -348,6 +458,135 @@ __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) 
     count_rays(A.rays, nrays);
 }
 
+// ---- kernel: first stage of the pipeline, bounce 0 of every pixel ---------------------------------
+// Persistent waves (the scene is staged into LDS once per workgroup, not once per 8 tiles); every
+// wave takes pairs of horizontally adjacent 8x8 tiles from an atomic counter, two pixels per lane
+// (x, y) and (x+8, y), and runs the primary rays and then the shadow rays of both pixels through
+// trace_hoisted_pair.  Pixels whose path ends at bounce 0 (miss, or maxBounces == 1) are written;
+// the others are appended to the path queue for trace_paths.
+template <int WAVES, bool SGN, bool W_LDS, int CAP>
+__global__ __launch_bounds__(64 * WAVES, 4) void first_bounce(const RtFrameArgs A) {   // 4 waves/SIMD: <= 128 VGPRs
+    extern __shared__ float4 lds[];
+    const uint32_t N16 = A.N16;
+    float4* sL = lds;
+    float4* sC = lds + N16;
+    float* sLw = reinterpret_cast<float*>(lds + 2 * N16);
+    float* sCw = sLw + N16;
+    uint32_t* lists = reinterpret_cast<uint32_t*>(sLw + (W_LDS ? 2 * N16 : 0));
+    for (uint32_t i = threadIdx.x; i < N16; i += 64 * WAVES) {
+        sL[i] = A.lgt_f[i];
+        sC[i] = A.cam_f[i];
+        if (W_LDS) { sLw[i] = A.lgt_w[i]; sCw[i] = A.cam_w[i]; }
+    }
+    __syncthreads();
+    const float* Lw = W_LDS ? sLw : A.lgt_w;
+    const float* Cw = W_LDS ? sCw : A.cam_w;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* slot0 = lists + wave * (uint32_t)(2 * CAP * 64) + lane;
+    uint32_t* slot1 = slot0 + CAP * 64;
+
+    const Scene sc = unpack_scene(A);
+    const uint32_t pairs_x = (A.W + 15u) / 16u;
+    const uint32_t total_pairs = pairs_x * A.n_local_tiles;
+    uint32_t nrays = 0;
+
+    for (;;) {
+        uint32_t pair = 0;
+        if (lane == 0) pair = atomicAdd(&A.qctrl[2], 1u);
+        pair = __builtin_amdgcn_readfirstlane(pair);
+        if (pair >= total_pairs) break;
+        const uint32_t ty = pair / pairs_x, px = pair - ty * pairs_x;
+        const uint32_t row = lane >> 3;
+        const uint32_t y = (A.tile_first + ty * A.tile_step) * 8u + row;
+        const uint32_t xs[2] = {px * 16u + (lane & 7u), px * 16u + 8u + (lane & 7u)};
+        bool in[2], hit[2] = {false, false};
+        v3 dir0[2], color[2], ro[2], rd[2], normal[2], sdir[2], albedo[2];
+        float dist[2], distance[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            in[j] = xs[j] < A.W && y < A.H;                        // RR:445: outside the texture: nothing
+            dir0[j] = primary_dir(A, sc, in[j] ? xs[j] : 0u, in[j] ? y : 0u);
+            color[j] = V(1.0f, 1.0f, 1.0f);                         // RK:103
+            dist[j] = 0.0f;                                         // RK:102
+            ro[j] = sc.cameraPos; rd[j] = dir0[j];
+            normal[j] = sdir[j] = albedo[j] = V(0.0f, 0.0f, 1.0f);
+            distance[j] = 1.0f;
+        }
+        const bool trace = sc.bounces > 0u;
+        if (trace) {
+            // ---- RK:114, bounce 0: primary rays (origin = camera for every lane) ----
+            float t[2]; int idx[2];
+            trace_hoisted_pair<SGN, CAP>(sC, Cw, N16, slot0, slot1, rd[0], rd[1], in[0], in[1], t[0], idx[0], t[1], idx[1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!in[j]) continue;
+                ++nrays;
+                hit[j] = idx[j] >= 0;
+                dist[j] = hit[j] ? t[j] : 0.0f;                                    // RK:116-118
+                if (!hit[j]) {                                                     // RK:122-126, next = 1 + 0
+                    const v3 sky = scale(sc.minIntensity, cube_sample(A, rd[j]));
+                    color[j] = divs(add(scale(0.0f, color[j]), scale(1.0f, sky)), 1.0f);
+                } else {
+                    const float4 g = A.geo[idx[j]];
+                    const float4 cl4 = A.col[idx[j]];
+                    albedo[j] = V(cl4.x, cl4.y, cl4.z);
+                    const v3 pos = add(ro[j], scale(t[j], rd[j]));                 // RK:129
+                    normal[j] = normalize(sub(pos, V(g.x, g.y, g.z)));             // HK:320
+                    ro[j] = pos;
+                    rd[j] = normalize(reflect(rd[j], normal[j]));                  // RK:130
+                    sdir[j] = normalize(sub(ro[j], sc.lightPos));                  // RK:147
+                    distance[j] = length(sdir[j]);                                 // RK:148
+                }
+            }
+            // ---- RK:153: shadow rays of the pixels that hit (origin = light) ----
+            if (__ballot(hit[0] || hit[1]) != 0ull) {
+                float st[2]; int sidx[2];
+                trace_hoisted_pair<SGN, CAP>(sL, Lw, N16, slot0, slot1, sdir[0], sdir[1], hit[0], hit[1],
+                                             st[0], sidx[0], st[1], sidx[1]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!hit[j]) continue;
+                    ++nrays;
+                    const float intensity = light_term(sc, ro[j], normal[j], sdir[j], distance[j], sidx[j] >= 0, st[j]);
+                    const v3 blended = scale(intensity, albedo[j]);                // RK:133-135
+                    color[j] = divs(add(scale(0.0f, color[j]), scale(1.0f, blended)), 1.0f);   // RK:136, sum 0, affect 1
+                }
+            }
+        }
+        // ---- hand over or finish ----
+        bool cont[2];
+        uint32_t opix[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            opix[j] = (ty * 8u + row) * A.W + xs[j];
+            cont[j] = in[j] && hit[j] && sc.bounces > 1u;
+        }
+        const uint64_t m0 = __ballot(cont[0]), m1 = __ballot(cont[1]);
+        if (m0 | m1) {
+            const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.qctrl[0], n0 + n1);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!cont[j]) continue;
+                const uint32_t e = base + (j ? n0 + (uint32_t)__popcll(m1 & below) : (uint32_t)__popcll(m0 & below));
+                float4* q = A.queue + 3u * (size_t)e;
+                q[0] = make_float4(ro[j].x, ro[j].y, ro[j].z, __uint_as_float(opix[j]));
+                q[1] = make_float4(rd[j].x, rd[j].y, rd[j].z, dist[j]);
+                q[2] = make_float4(color[j].x, color[j].y, color[j].z, 0.0f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (in[j] && !cont[j])
+                reinterpret_cast<uint32_t*>(A.out)[opix[j]] = compose_pixel(A, sc, dir0[j], color[j], dist[j]);   // RK:91-98
+    }
+    count_rays(A.rays, nrays);
+}
+
 // ---- kernel: second stage of the pipeline, bounces 1.. with path regeneration -------------------
 // Persistent waves: every lane carries one path; a lane whose path ends (miss RK:122-126, or
 // the bounce limit) takes the next entry of the path queue, so the per-lane-origin trace (the
@@ -467,7 +706,7 @@ __global__ void prep_spheres(const RtPrepArgs A) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.N16) return;
     if (i >= A.N) {   // padding records: can never pass the filter
-        A.geo_f[i] = make_float4(0.0f, 0.0f, 0.0f, -INFINITY);
+        A.geo_f[i] = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
         A.lgt_f[i] = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
         A.cam_f[i] = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
         A.geo_w[i] = 0.0f; A.lgt_w[i] = 0.0f; A.cam_w[i] = 0.0f;
@@ -487,7 +726,10 @@ __global__ void prep_spheres(const RtPrepArgs A) {
     A.geo_w[i] = r2; A.lgt_w[i] = ll - r2; A.cam_w[i] = cc - r2;
     const float S = RT_FILTER_SCALE, S2 = RT_FILTER_SCALE2;
     const float r2f = r2 * (1.0f + RT_FILTER_KAPPA);
-    A.geo_f[i] = make_float4(c.x * S, c.y * S, c.z * S, r2f * S2);
+    // expanded form: k = |c|^2 (1-eps) - r^2 (1+kappa), formed in double, rounded once
+    const double cd2 = (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z;
+    const double kf = cd2 * (1.0 - (double)RT_FILTER_EPS) - (double)r2 * (1.0 + (double)RT_FILTER_KAPPA);
+    A.geo_f[i] = make_float4(c.x * S, c.y * S, c.z * S, (float)(kf * (double)S2));
     A.lgt_f[i] = make_float4(lo.x * S, lo.y * S, lo.z * S, (ll - r2f) * S2);
     A.cam_f[i] = make_float4(co.x * S, co.y * S, co.z * S, (cc - r2f) * S2);
 }
@@ -547,6 +789,28 @@ hipError_t launch_paths(const RtFrameArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int WAVES, bool W_LDS, int CAP>
+size_t lds_first(const RtFrameArgs& a) {
+    return (size_t)a.N16 * 32u + (W_LDS ? (size_t)a.N16 * 8u : 0u) + (size_t)WAVES * 2u * CAP * 256u;
+}
+
+template <int WAVES, bool SGN, bool W_LDS, int CAP>
+hipError_t launch_first(const RtFrameArgs& a, hipStream_t s) {
+    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    const size_t lds = lds_first<WAVES, W_LDS, CAP>(a);
+    if (lds > kLdsCap) return hipErrorInvalidValue;
+    auto k = first_bounce<WAVES, SGN, W_LDS, CAP>;
+    hipError_t e = set_lds(k, lds);
+    if (e != hipSuccess) return e;
+    const uint32_t per_cu = (uint32_t)min((size_t)(32 / WAVES), kLdsCap / lds);
+    const uint32_t pairs = ((a.W + 15u) / 16u) * a.n_local_tiles;
+    uint32_t blocks = 256u * (per_cu ? per_cu : 1u);
+    const uint32_t need = (pairs + WAVES - 1u) / WAVES;
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
+    return hipGetLastError();
+}
+
 // RT_MODE_STRICT: one literal kernel, exact records in LDS
 hipError_t launch_strict(const RtFrameArgs& a, hipStream_t s) {
     const size_t bytes = (size_t)a.N * 48u;
@@ -566,17 +830,19 @@ hipError_t launch_fast(const RtFrameArgs& a, int variant, hipStream_t s) {
                   // single kernel for small scenes (the queue round trip costs more than it saves)
             if (pipeline) {
                 hipError_t e;
-                if (2 * rec + rec / 2 + 8u * 16u * 256u <= 80u * 1024u) {        // N <= ~1200
-                    e = launch_pixels<8, true, true, SGN, true, 16>(a, s);
-                    if (e != hipSuccess) return e;
-                    return launch_paths<8, SGN, true, 16>(a, s);
-                }
                 if (lds_paths<8, true, 16>(a) <= kLdsCap) {                      // N <= ~3600
-                    e = launch_pixels<8, true, true, SGN, true, 16>(a, s);
+                    e = launch_first<8, SGN, true, 8>(a, s);
                     if (e != hipSuccess) return e;
                     return launch_paths<8, SGN, true, 16>(a, s);
                 }
-                e = launch_pixels<8, true, true, SGN, false, 8>(a, s);           // N <= 5120: w from global
+                // larger scenes: exact 4th components from global memory; 16-wave workgroups so
+                // that the one workgroup a CU can hold still gives 4 waves per SIMD
+                if (lds_paths<16, false, 8>(a) <= kLdsCap) {                     // N <= 4096
+                    e = launch_first<16, SGN, false, 4>(a, s);
+                    if (e != hipSuccess) return e;
+                    return launch_paths<16, SGN, false, 8>(a, s);
+                }
+                e = launch_first<8, SGN, false, 4>(a, s);                        // N <= 4608
                 if (e != hipSuccess) return e;
                 return launch_paths<8, SGN, false, 8>(a, s);
             }

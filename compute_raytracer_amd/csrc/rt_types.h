@@ -5,6 +5,8 @@
 
 // Relative safety margin of the conservative discriminant filter (see rt_kernels.hip).
 #define RT_FILTER_KAPPA 1.52587890625e-05f   // 2^-16
+// Extra margin of the expanded form used for per-lane ray origins: eps * (|o|^2 + |c|^2).
+#define RT_FILTER_EPS 7.62939453125e-06f     // 2^-17 = 128 * 2^-24
 // Filter records hold positions scaled by 2^40 (exact: a power of two) so that the filter's
 // discriminant is scaled by 2^80: whenever it is positive it is >= 1 (it is a difference of
 // numbers whose granularity exceeds 1, see rt_kernels.hip), and the `clamp` output modifier of
@@ -28,7 +30,7 @@ struct RtFrameArgs {
     const float4* cam;         // same for ray origin = camera       (primary rays)
     const float4* col;         // {r, g, b, 0}
     // filter records, [N16]: scaled, inflated copies for the conservative discriminant test
-    const float4* geo_f;       // {c * 2^40, r*r*(1+kappa) * 2^80}                pad: w = -inf
+    const float4* geo_f;       // {c * 2^40, (|c|^2 (1-eps) - r*r*(1+kappa)) * 2^80}   pad: w = +inf
     const float4* lgt_f;       // {(L-c) * 2^40, (|L-c|^2 - r*r*(1+kappa)) * 2^80}  pad: w = +inf
     const float4* cam_f;       // same for the camera
     // exact 4th components next to the filter records, [N16] (xyz is recovered exactly as *2^-40)
@@ -42,7 +44,8 @@ struct RtFrameArgs {
     // path queue between the first-bounce kernel and the path kernel (two-kernel pipeline):
     // 3 float4 per surviving path {ro.xyz, pixel index}, {rd.xyz, dist}, {color.rgb, 0}
     float4* queue;             // [queue_cap][3]
-    uint32_t* qctrl;           // [0] entries appended by the first-bounce kernel, [1] pop cursor
+    uint32_t* qctrl;           // [0] entries appended by the first-bounce kernel, [1] pop cursor,
+                               // [2] tile-pair cursor of the first-bounce kernel
     uint32_t queue_cap;
 };
 
