@@ -204,7 +204,7 @@ def main():
                        "mode": a.mode, "variant": a.variant, "rays_per_frame": rays_frame,
                        "parallelism": "row-tiles x%d%s" % (world, "" if world == 1 else " + RCCL all-gather")},
             "roofline": {
-                "bound": "valu-fp32", "kernel": "trace_pixels",
+                "bound": "valu-fp32", "kernel": "first_bounce + trace_paths (one frame's ray-trace launches)",
                 "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP32_TFLOPS,
                 "traffic": traffic,
