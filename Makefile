@@ -4,7 +4,7 @@ ARCH     ?= gfx950
 CSRC     := compute_raytracer_amd/csrc
 LIB      := compute_raytracer_amd/librt355.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-fast-math -Wall -Wno-unused-function
-OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_assemble.o
+OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_triangles.o $(CSRC)/rt_assemble.o
 
 all: lib oracle node
 
@@ -15,10 +15,13 @@ lib: $(LIB)
 $(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_types.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -fno-slp-vectorize -c $< -o $@
 
+$(CSRC)/rt_triangles.o: $(CSRC)/rt_triangles.hip $(CSRC)/rt_device.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -fno-slp-vectorize -c $< -o $@
+
 $(CSRC)/rt_assemble.o: $(CSRC)/rt_assemble.hip $(CSRC)/rt_types.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/rt_api.o: $(CSRC)/rt_api.hip $(CSRC)/rt_types.h include/rt355.h
+$(CSRC)/rt_api.o: $(CSRC)/rt_api.hip $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h include/rt355.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

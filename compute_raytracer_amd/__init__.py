@@ -18,10 +18,15 @@ from .light import Light
 from .sphere import Sphere
 from .scene_raytracing import SceneRaytracing, synthetic_scene, BASELINE_CONFIGS
 from .cubemap_material import CubemapMaterial
+from .material import Material
+from .mesh import Mesh
+from .model import Model, Triangle
+from .acceleration import AABB, BLAS, BVH, Node
 from .renderer_raytracing import RendererRaytracing
 from . import abi, tiles
 
 __all__ = [
     "Camera", "Light", "Sphere", "SceneRaytracing", "synthetic_scene", "BASELINE_CONFIGS",
-    "CubemapMaterial", "RendererRaytracing", "abi", "tiles",
+    "CubemapMaterial", "Material", "Mesh", "Model", "Triangle", "AABB", "BLAS", "BVH", "Node",
+    "RendererRaytracing", "abi", "tiles",
 ]

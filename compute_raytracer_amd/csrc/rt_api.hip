@@ -4,6 +4,7 @@
 // rt_create fails and nothing else can be called.
 #include "../../include/rt355.h"
 #include "rt_types.h"
+#include "rt_tri_types.h"
 
 #include <cmath>
 #include <cstdio>
@@ -61,6 +62,11 @@ struct rt_ctx {
     float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
     size_t queue_cap = 0;                  // entries
     unsigned long long* h_rays = nullptr;  // pinned
+    // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
+    struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };
+    DevBuf d_tri, d_nodes, d_blas, d_tri_lookup, d_blas_lookup, d_tex;
+    uint32_t tex_w = 0, tex_h = 0;
+    int scene_kind = 0;                    // 0 spheres, 1 triangles: the primitive type written last
     int mode = RT_MODE_FAST;
     int variant = 0;
     int kernel = RT_KERNEL_RAYTRACER;
@@ -125,6 +131,8 @@ int rt_destroy(rt_ctx* c) {
     for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
     (void)hipFree(c->d_out);
     (void)hipFree(c->d_queue);
+    for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_nodes, &c->d_blas, &c->d_tri_lookup, &c->d_blas_lookup, &c->d_tex})
+        (void)hipFree(b->p);
     (void)hipFree(c->d_rays);
     if (c->h_rays) (void)hipHostFree(c->h_rays);
     for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) {
@@ -225,6 +233,7 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
         RT_HIP(hipStreamSynchronize(c->stream));   // caller may free `records` now (writeBuffer semantics)
     }
     c->n = n;
+    c->scene_kind = 0;
     c->n16 = (n + 15u) & ~15u;
     {   // scene extent, for the sign-aware filter (rt_kernels.hip: filter_one)
         double bound = 0.0;
@@ -261,21 +270,75 @@ int rt_write_cubemap_face(rt_ctx* c, int face, uint32_t w, uint32_t h, const uin
     return RT_OK;
 }
 
-#define RT_UNSUPPORTED(name)                                                                      \
-    return fail(RT_ERR_UNSUPPORTED, name ": the triangle/BVH path (SURVEY.md 8(f) row 1) is not built yet")
+// writeBuffer(buffer, byte_offset, data): grows the device buffer when needed (keeping what is
+// already there), copies, and returns once the caller's memory is no longer needed
+static int write_buf(rt_ctx* c, rt_ctx::DevBuf& b, size_t byte_offset, const void* data, size_t bytes, const char* who) {
+    RT_HIP(hipSetDevice(c->device));
+    const size_t need = byte_offset + bytes;
+    if (need > b.cap) {
+        RT_HIP(hipStreamSynchronize(c->stream));
+        if (c->last_stream != c->stream && c->in_flight) RT_HIP(hipStreamSynchronize(c->last_stream));
+        void* np = nullptr;
+        const size_t cap = need < 256 ? 256 : need;
+        RT_HIP(hipMalloc(&np, cap));
+        RT_HIP(hipMemsetAsync(np, 0, cap, c->stream));
+        if (b.p && b.used) RT_HIP(hipMemcpyAsync(np, b.p, b.used, hipMemcpyDeviceToDevice, c->stream));
+        RT_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(b.p);
+        b.p = np;
+        b.cap = cap;
+    }
+    if (bytes) {
+        if (!data) return fail(RT_ERR_INVALID_ARG, who);
+        RT_HIP(hipMemcpyAsync(static_cast<char*>(b.p) + byte_offset, data, bytes, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (need > b.used) b.used = need;
+    return RT_OK;
+}
 
-int rt_write_triangles(rt_ctx*, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_triangles"); }
-int rt_write_nodes(rt_ctx*, size_t, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_nodes"); }
-int rt_write_blas(rt_ctx*, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_blas"); }
-int rt_write_tri_lookup(rt_ctx*, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_tri_lookup"); }
-int rt_write_blas_lookup(rt_ctx*, const float*, uint32_t) { RT_UNSUPPORTED("rt_write_blas_lookup"); }
-int rt_write_mesh_texture(rt_ctx*, uint32_t, uint32_t, const uint8_t*) { RT_UNSUPPORTED("rt_write_mesh_texture"); }
+int rt_write_triangles(rt_ctx* c, const float* data, uint32_t n) {                    // RR:198-209
+    if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_triangles: NULL argument");
+    c->d_tri.used = 0;
+    int rc = write_buf(c, c->d_tri, 0, data, (size_t)n * 160u, "rt_write_triangles: NULL data");
+    if (rc == RT_OK) c->scene_kind = 1;
+    return rc;
+}
+int rt_write_nodes(rt_ctx* c, size_t byte_offset, const float* data, uint32_t n) {    // RR:184-192, 212-223
+    if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_nodes: NULL argument");
+    if (byte_offset % 32u) return fail(RT_ERR_INVALID_ARG, "rt_write_nodes: byte_offset must be a multiple of the 32-byte node");
+    int rc = write_buf(c, c->d_nodes, byte_offset, data, (size_t)n * 32u, "rt_write_nodes: NULL data");
+    if (rc == RT_OK) c->scene_kind = 1;
+    return rc;
+}
+int rt_write_blas(rt_ctx* c, const float* data, uint32_t n) {                         // RR:169-174
+    if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_blas: NULL argument");
+    c->d_blas.used = 0;
+    return write_buf(c, c->d_blas, 0, data, (size_t)n * 80u, "rt_write_blas: NULL data");
+}
+int rt_write_tri_lookup(rt_ctx* c, const float* data, uint32_t n) {                   // RR:225-229
+    if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_tri_lookup: NULL argument");
+    c->d_tri_lookup.used = 0;
+    return write_buf(c, c->d_tri_lookup, 0, data, (size_t)n * 4u, "rt_write_tri_lookup: NULL data");
+}
+int rt_write_blas_lookup(rt_ctx* c, const float* data, uint32_t n) {                  // RR:177-181
+    if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_blas_lookup: NULL argument");
+    c->d_blas_lookup.used = 0;
+    return write_buf(c, c->d_blas_lookup, 0, data, (size_t)n * 4u, "rt_write_blas_lookup: NULL data");
+}
+int rt_write_mesh_texture(rt_ctx* c, uint32_t w, uint32_t h, const uint8_t* rgba) {   // material.ts:61-65
+    if (!c || !rgba) return fail(RT_ERR_INVALID_ARG, "rt_write_mesh_texture: NULL argument");
+    if (w == 0 || h == 0 || w > 16384u || h > 16384u)
+        return fail(RT_ERR_INVALID_ARG, "rt_write_mesh_texture: size must be in 1..16384");
+    c->d_tex.used = 0;
+    int rc = write_buf(c, c->d_tex, 0, rgba, (size_t)w * h * 4u, "rt_write_mesh_texture: NULL data");
+    if (rc == RT_OK) { c->tex_w = w; c->tex_h = h; }
+    return rc;
+}
 
 int rt_select_kernel(rt_ctx* c, int kernel) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_select_kernel: ctx is NULL");
-    if (kernel == RT_KERNEL_RAYTRACER) { c->kernel = kernel; return RT_OK; }
-    if (kernel == RT_KERNEL_HEATMAP)
-        return fail(RT_ERR_UNSUPPORTED, "rt_select_kernel: the heatmap kernel (SURVEY.md 8(f) row 4) is not built yet");
+    if (kernel == RT_KERNEL_RAYTRACER || kernel == RT_KERNEL_HEATMAP) { c->kernel = kernel; return RT_OK; }
     return fail(RT_ERR_INVALID_ARG, "rt_select_kernel: unknown kernel");
 }
 
@@ -296,7 +359,19 @@ int rt_set_variant(rt_ctx* c, int variant) {
 static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     if (!c->W || !c->H) return fail(RT_ERR_STATE, "rt_render: rt_resize has not been called");
     if (!c->have_params) return fail(RT_ERR_STATE, "rt_render: rt_write_params has not been called");
-    if (!c->have_spheres) return fail(RT_ERR_STATE, "rt_render: rt_write_spheres has not been called");
+    const bool tri = c->scene_kind == 1;
+    if (!tri && !c->have_spheres) return fail(RT_ERR_STATE, "rt_render: rt_write_spheres has not been called");
+    if (tri) {
+        if (!c->d_tri.used || !c->d_nodes.used || !c->d_blas.used || !c->d_tri_lookup.used || !c->d_blas_lookup.used)
+            return fail(RT_ERR_STATE, "rt_render: a triangle scene needs rt_write_triangles, _nodes, _blas, _tri_lookup and _blas_lookup");
+        if (!c->d_tex.used) {   // meshTex is mandatory in the reference (RR:113-114); default: 1x1 white
+            const uint8_t white[4] = {255, 255, 255, 255};
+            int rc = rt_write_mesh_texture(c, 1, 1, white);
+            if (rc != RT_OK) return rc;
+        }
+    } else if (c->kernel == RT_KERNEL_HEATMAP) {
+        return fail(RT_ERR_UNSUPPORTED, "rt_render: the heatmap kernel counts BVH traversal steps; sphere scenes have no BVH");
+    }
     for (int i = 0; i < 6; ++i)
         if (!c->d_face[i]) return fail(RT_ERR_STATE, "rt_render: all six cube map faces must be written first");
     RT_HIP(hipSetDevice(c->device));
@@ -312,7 +387,7 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
 
     RT_HIP(hipEventRecord(c->ev_prep0[slot], s));
     if (s != c->stream) c->scene_dirty = true;   // no ordering between streams is assumed
-    if (c->scene_dirty && c->n) {
+    if (!tri && c->scene_dirty && c->n) {
         RtPrepArgs pa;
         std::memcpy(pa.p, c->params, sizeof pa.p);
         pa.N = c->n; pa.N16 = c->n16;
@@ -340,7 +415,7 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         const float* w = reinterpret_cast<const float*>(b + 7u * m);
         fa.geo_w = w; fa.lgt_w = w + m; fa.cam_w = w + 2u * m;
     }
-    if ((size_t)c->n16 * 2u * sizeof(float4) + 8u * 8u * 256u > 160u * 1024u)
+    if (!tri && (size_t)c->n16 * 2u * sizeof(float4) + 8u * 8u * 256u > 160u * 1024u)
         return fail(RT_ERR_UNSUPPORTED, "rt_render: more than 4608 spheres need chunked LDS staging (not built yet)");
     {   // sign-aware filter only while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays
         // below half of the 0.001 a valid hit needs (rt_kernels.hip: filter_one)
@@ -363,7 +438,24 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     cfg.variant = c->variant;
 
     RT_HIP(hipEventRecord(c->ev_k0[slot], s));
-    RT_HIP(rt_launch_trace(fa, cfg, s));
+    if (tri) {
+        RtTriScene ts;
+        ts.nodes = static_cast<const float4*>(c->d_nodes.p);
+        ts.blas = static_cast<const float*>(c->d_blas.p);
+        ts.tri = static_cast<const float*>(c->d_tri.p);
+        ts.tri_lookup = static_cast<const float*>(c->d_tri_lookup.p);
+        ts.blas_lookup = static_cast<const float*>(c->d_blas_lookup.p);
+        ts.tex = static_cast<const uint8_t*>(c->d_tex.p);
+        ts.n_nodes = (uint32_t)(c->d_nodes.used / 32u);
+        ts.n_blas = (uint32_t)(c->d_blas.used / 80u);
+        ts.n_tri = (uint32_t)(c->d_tri.used / 160u);
+        ts.n_tri_lookup = (uint32_t)(c->d_tri_lookup.used / 4u);
+        ts.n_blas_lookup = (uint32_t)(c->d_blas_lookup.used / 4u);
+        ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
+        RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
+    } else {
+        RT_HIP(rt_launch_trace(fa, cfg, s));
+    }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
     RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     c->last_stream = s;

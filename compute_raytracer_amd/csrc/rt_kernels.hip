@@ -14,9 +14,10 @@
 //   * sphere records are SoA float4 staged in LDS: one ds_read_b128 with a wave-uniform address
 //     feeds one ray-sphere test of the whole wave (an SGPR operand would halve the FMA rate);
 //   * only v_fma_f32 issues at ~2 cycles per wave on gfx950 (v_add/v_mul ~3.5, v_max/v_cmp ~4.5):
-//     the per-sphere filter is written as v_fma_f32 only -- 11 for a ray with a per-lane origin,
-//     5 for rays from the camera or the light -- and leaves a per-lane BIT MASK of the spheres
-//     that may be hit, built in the FMA pipe (clamp turns "positive" into 1.0; Horner sum);
+//     the per-sphere filter is written as v_fma_f32 only -- 9 for a ray with a per-lane origin,
+//     6 for rays from the camera or the light, mask update included -- and leaves a per-lane BIT
+//     MASK of the spheres that may be hit, built in the FMA pipe (clamp turns "positive" into 1.0;
+//     Horner sum);
 //   * rays that start at one point for all lanes (primary rays at the camera, shadow rays at
 //     the light, RK:151) use records with `origin - center` and `c` precomputed per frame;
 //   * exactness: the filter decides only "can this sphere have discriminant > 0 in front of

@@ -1,0 +1,15 @@
+// rt_tri_types.h -- device view of the reference's triangle scene, byte layouts of RR:169-229.
+#pragma once
+#include "rt_types.h"
+
+struct RtTriScene {
+    const float4* nodes;       // [n_nodes][2]  {min.xyz, leftChildIndex}, {max.xyz, primitiveCount}
+    const float* blas;         // [n_blas][20]  inverseModel (column-major), rootNodeIndex, pad
+    const float* tri;          // [n_tri][40]   RR:198-209
+    const float* tri_lookup;   // [n_tri_lookup] f32 indices
+    const float* blas_lookup;  // [n_blas_lookup] f32 indices
+    const uint8_t* tex;        // meshTex, rgba8unorm
+    uint32_t n_nodes, n_blas, n_tri, n_tri_lookup, n_blas_lookup, tex_w, tex_h;
+};
+
+hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);

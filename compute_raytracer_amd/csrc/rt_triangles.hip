@@ -1,0 +1,322 @@
+// rt_triangles.hip -- the reference's LIVE scene type on gfx950: triangles behind a two-level
+// BVH (TLAS over model instances, one BLAS per mesh), SURVEY.md 8(f) row 1, and the heatmap twin
+// of the kernel (row 4).  Compiled like rt_kernels.hip with -ffp-contract=off: every floating
+// point expression is the reference's, correctly rounded, in the reference's order, so frames are
+// bit-identical to oracle/rt_oracle.c (rt_oracle_render_tri / rt_oracle_heatmap_tri).
+//
+// Reference (citations relative to the reference repository):
+//   RK = src/rendering-raycast/shaders/raytracer-kernel.wgsl   traceTLAS RK:168-244, traceBLAS
+//        RK:246-341, hitTriangle RK:344-393, hitAABB RK:395-410
+//   HK = src/rendering-raycast/shaders/heatmap-kernel.wgsl     main HK:63-83, counters HK:143,242,279
+// Buffers arrive in exactly the byte layouts RendererRaytracing writes (RR:169-229): 160-B
+// triangles, 32-B nodes, 80-B BLAS records, f32 lookup tables.
+//
+// CDNA4 mapping: one pixel per lane, 8x8 tile per wave64; the two traversal stacks of a lane
+// (`array<u32, 20>` each in the WGSL) live in LDS, slot-major ([slot][thread]) so that a wave's
+// push or pop touches 64 different banks; nodes are read as two float4 (the 32-B node is
+// exactly {min.xyz, leftChild | max.xyz, count}); interpolated normal, texture coordinate and
+// the normal's model transform are formed once for the final nearest hit (they depend only on
+// the winning triangle, its barycentrics and its BLAS, so deferring them is bit-exact).
+// Out-of-range indices follow the robustness rule the oracle fixes (clamp to the last element).
+#include "rt_device.h"
+#include "rt_tri_types.h"
+
+namespace rtk {
+
+constexpr uint32_t kStack = 20u;                                  // RK:71
+
+__device__ __forceinline__ uint32_t u32f(float f) {               // WGSL u32(f32)
+    if (!(f > 0.0f)) return 0u;
+    return f >= 4294967040.0f ? 4294967295u : (uint32_t)f;
+}
+__device__ __forceinline__ uint32_t sclamp(uint32_t i) { return i > kStack - 1u ? kStack - 1u : i; }
+
+struct NodeR { v3 lo; float left; v3 hi; float count; };
+__device__ __forceinline__ NodeR load_node(const RtTriScene& T, uint32_t i) {
+    if (i >= T.n_nodes) i = T.n_nodes - 1u;
+    const float4 a = T.nodes[2u * (size_t)i], b = T.nodes[2u * (size_t)i + 1u];
+    NodeR n;
+    n.lo = V(a.x, a.y, a.z); n.left = a.w;
+    n.hi = V(b.x, b.y, b.z); n.count = b.w;
+    return n;
+}
+
+// RK:395-410
+__device__ __forceinline__ float hit_aabb(v3 o, v3 inv, const NodeR& n) {
+    const v3 t1 = V((n.lo.x - o.x) * inv.x, (n.lo.y - o.y) * inv.y, (n.lo.z - o.z) * inv.z);   // RK:397
+    const v3 t2 = V((n.hi.x - o.x) * inv.x, (n.hi.y - o.y) * inv.y, (n.hi.z - o.z) * inv.z);   // RK:398
+    const float t_min = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1.z, t2.z)); // RK:399,402
+    const float t_max = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z)); // RK:400,403
+    if (t_min > t_max || t_max < 0.0f) return 99999.0f;                                        // RK:405-407
+    return t_min;
+}
+
+__device__ __forceinline__ v3 cross3(v3 a, v3 b) {
+    return V(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+
+struct TriHit {       // what survives of RenderState during traversal
+    float t, u, v;
+    int tri, blas;    // tri < 0: no hit
+};
+
+// RK:344-381, up to the acceptance test; normal / uv / colour are formed later for the winner
+__device__ __forceinline__ bool hit_triangle(const RtTriScene& T, uint32_t ti, v3 o, v3 d, float tMax,
+                                             float& t_out, float& u_out, float& v_out) {
+    const float4* tr = reinterpret_cast<const float4*>(T.tri + 40u * (size_t)ti);
+    const float4 A = tr[0], B = tr[3], C = tr[6];                   // corner k at float 12k
+    const v3 cornerA = V(A.x, A.y, A.z);
+    const v3 edge1 = sub(V(B.x, B.y, B.z), cornerA);                // RK:354
+    const v3 edge2 = sub(V(C.x, C.y, C.z), cornerA);                // RK:355
+    const v3 rayCrossEdge2 = cross3(d, edge2);                      // RK:356
+    const float det = dot(edge1, rayCrossEdge2);                    // RK:357
+    if (det < 0.00001f) return false;                               // RK:359-362 (back faces culled)
+    const v3 s = sub(o, cornerA);                                   // RK:364
+    float u = dot(s, rayCrossEdge2);                                // RK:365
+    if (u < 0.0f || u > det) return false;                          // RK:366
+    const v3 sCrossEdge1 = cross3(s, edge1);                        // RK:370
+    float v = dot(d, sCrossEdge1);                                  // RK:371
+    if (v < 0.0f || u + v > det) return false;                      // RK:372
+    const float invDet = 1.0f / det;                                // RK:376
+    const float t = invDet * dot(edge2, sCrossEdge1);               // RK:377
+    u = u * invDet;                                                 // RK:378
+    v = v * invDet;                                                 // RK:379
+    if (t > 0.001f && t < tMax) {                                   // RK:380 (tMin 0.001, RK:315)
+        t_out = t; u_out = u; v_out = v;
+        return true;
+    }
+    return false;
+}
+
+// RK:246-332 traceBLAS (the normal transform RK:334-338 is deferred to finish_hit)
+template <bool COUNT>
+__device__ __forceinline__ void trace_blas(const RtTriScene& T, uint32_t bi, v3 o, v3 d, float& nearest,
+                                           TriHit& hit, uint32_t* stack, uint32_t stride, float& traces) {
+    const float* m = T.blas + 20u * (size_t)bi;                     // mat4 column-major, m[4c + r]
+    const v3 oo = V(((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.0f,
+                    ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.0f,
+                    ((m[2] * o.x + m[6] * o.y) + m[10] * o.z) + m[14] * 1.0f);       // RK:254
+    const v3 od = V(((m[0] * d.x + m[4] * d.y) + m[8] * d.z) + m[12] * 0.0f,
+                    ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.0f,
+                    ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.0f);       // RK:255
+    const v3 inv = V(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);        // RK:396
+    NodeR node = load_node(T, u32f(m[16]));                         // RK:265
+    uint32_t sp = 0;                                                // RK:267
+    float blasNearest = nearest;                                    // RK:269
+    for (;;) {                                                      // RK:271
+        const uint32_t count = u32f(node.count);                    // RK:272
+        const uint32_t left = u32f(node.left);                      // RK:273
+        if (count == 0u) {                                          // RK:275
+            if (COUNT) traces += 2.0f;                              // HK:242
+            uint32_t i1 = left, i2 = left + 1u;
+            const NodeR c1 = load_node(T, left), c2 = load_node(T, left + 1u);
+            float d1 = hit_aabb(oo, inv, c1);                       // RK:279
+            float d2 = hit_aabb(oo, inv, c2);                       // RK:280
+            const bool swap = d1 > d2;                              // RK:283-290
+            if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; i1 = left + 1u; i2 = left; }
+            if (d1 > blasNearest) {                                 // RK:292
+                if (sp == 0u) break;
+                sp -= 1u;
+                node = load_node(T, stack[sclamp(sp) * stride]);    // RK:297-298
+            } else {
+                node = swap ? c2 : c1;                              // RK:302 tree[iChild1]
+                (void)i1;
+                if (d2 < blasNearest) {                             // RK:303
+                    stack[sclamp(sp) * stride] = i2;                // RK:304 (no overflow guard upstream)
+                    sp += 1u;
+                }
+            }
+        } else {
+            for (uint32_t i = 0; i < count; ++i) {                  // RK:311
+                uint32_t li = i + left;
+                if (li >= T.n_tri_lookup) li = T.n_tri_lookup - 1u;
+                uint32_t ti = u32f(T.tri_lookup[li]);               // RK:314
+                if (ti >= T.n_tri) ti = T.n_tri - 1u;
+                if (COUNT) traces += 1.0f;                          // HK:279
+                float t, u, v;
+                if (hit_triangle(T, ti, oo, od, blasNearest, t, u, v)) {   // RK:312-321
+                    blasNearest = t;
+                    hit.t = t; hit.u = u; hit.v = v; hit.tri = (int)ti; hit.blas = (int)bi;
+                }
+            }
+            if (sp == 0u) break;                                    // RK:324
+            sp -= 1u;
+            node = load_node(T, stack[sclamp(sp) * stride]);        // RK:328-329
+        }
+    }
+    nearest = blasNearest < nearest ? blasNearest : nearest;        // RK:227-229: nearestHit = newRenderState.t on a hit
+}
+
+// RK:168-244 traceTLAS.  tstack / bstack: this lane's two LDS stacks.
+template <bool COUNT>
+__device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, v3 o, v3 d, uint32_t* tstack, uint32_t* bstack,
+                                             uint32_t stride, float& traces) {
+    TriHit hit; hit.t = 0.0f; hit.u = hit.v = 0.0f; hit.tri = -1; hit.blas = -1;   // RK:170-171
+    float nearest = 9999.0f;                                        // RK:172
+    const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    NodeR node = load_node(T, 0u);                                  // RK:175
+    uint32_t sp = 0;
+    for (;;) {                                                      // RK:179
+        const uint32_t count = u32f(node.count);                    // RK:180
+        const uint32_t left = u32f(node.left);                      // RK:181
+        if (count == 0u) {                                          // RK:183
+            if (COUNT) traces += 2.0f;                              // HK:143
+            uint32_t i2 = left + 1u;
+            const NodeR c1 = load_node(T, left), c2 = load_node(T, left + 1u);
+            float d1 = hit_aabb(o, inv, c1);                        // RK:186
+            float d2 = hit_aabb(o, inv, c2);                        // RK:187
+            const bool swap = d1 > d2;                              // RK:190-196
+            if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; i2 = left; }
+            if (d1 > nearest) {                                     // RK:198
+                if (sp == 0u) break;
+                sp -= 1u;
+                node = load_node(T, tstack[sclamp(sp) * stride]);
+            } else {
+                node = swap ? c2 : c1;                              // RK:208
+                if (d2 < nearest) {                                 // RK:209
+                    tstack[sclamp(sp) * stride] = i2;
+                    sp += 1u;
+                    // RK:212-214 guards with `>`, the heatmap twin with `>=` (HK:168)
+                    if (COUNT ? sp >= kStack : sp > kStack) sp = kStack - 1u;
+                }
+            }
+        } else {
+            for (uint32_t i = 0; i < count; ++i) {                  // RK:220
+                uint32_t li = i + left;
+                if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
+                uint32_t bi = u32f(T.blas_lookup[li]);              // RK:223
+                if (bi >= T.n_blas) bi = T.n_blas - 1u;
+                trace_blas<COUNT>(T, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
+            }
+            if (sp == 0u) break;                                    // RK:233
+            sp -= 1u;
+            node = load_node(T, tstack[sclamp(sp) * stride]);       // RK:237-238
+        }
+    }
+    return hit;
+}
+
+// What hitTriangle (RK:381-387) and traceBLAS (RK:334-338) attach to the accepted hit.
+struct Surface { v3 normal; float u, v; v3 rgb; float w; };
+__device__ __forceinline__ Surface finish_hit(const RtTriScene& T, const TriHit& h) {
+    const float* tr = T.tri + 40u * (size_t)h.tri;
+    const float w = 1.0f - h.u - h.v;                                                // RK:381
+    const v3 nA = V(tr[4], tr[5], tr[6]), nB = V(tr[16], tr[17], tr[18]), nC = V(tr[28], tr[29], tr[30]);
+    const v3 n = add(add(scale(w, nA), scale(h.u, nB)), scale(h.v, nC));             // RK:382
+    Surface s;
+    s.u = (tr[8] * w + tr[20] * h.u) + tr[32] * h.v;                                 // RK:386
+    s.v = 1.0f - ((tr[9] * w + tr[21] * h.u) + tr[33] * h.v);                        // RK:386-387
+    s.rgb = V(tr[36], tr[37], tr[38]); s.w = tr[39];                                 // RK:384
+    const float* m = T.blas + 20u * (size_t)h.blas;
+    const v3 tn = V(((m[0] * n.x + m[1] * n.y) + m[2] * n.z) + m[3] * 0.0f,
+                    ((m[4] * n.x + m[5] * n.y) + m[6] * n.z) + m[7] * 0.0f,
+                    ((m[8] * n.x + m[9] * n.y) + m[10] * n.z) + m[11] * 0.0f);       // RK:335-337
+    s.normal = normalize(tn);
+    return s;
+}
+
+// textureSampleLevel(meshTex, texSamp, uv, 0).rgb with the cube map's sampler (RR:345-347):
+// U repeat, V clamp-to-edge, bilinear; arithmetic of oracle/rt_oracle.c:tex2d_sample
+__device__ inline v3 tex2d_sample(const RtTriScene& T, float u, float v) {
+    const int w = (int)T.tex_w, h = (int)T.tex_h;
+    const float x = u * (float)w - 0.5f;
+    const float y = v * (float)h - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float wx = x - fx, wy = y - fy;
+    const int x0 = fx >= 2147483520.0f ? 2147483520 : (fx <= -2147483520.0f ? -2147483520 : (int)fx);
+    const int y0 = fy >= 2147483520.0f ? 2147483520 : (fy <= -2147483520.0f ? -2147483520 : (int)fy);
+    const int xa = ((x0 % w) + w) % w, xb = (((x0 + 1) % w) + w) % w;
+    const int ya = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0);
+    const int yb = y0 + 1 < 0 ? 0 : (y0 + 1 > h - 1 ? h - 1 : y0 + 1);
+    const v3 c00 = texel(T.tex, w, h, xa, ya), c10 = texel(T.tex, w, h, xb, ya);
+    const v3 c01 = texel(T.tex, w, h, xa, yb), c11 = texel(T.tex, w, h, xb, yb);
+    return lerp3(lerp3(c00, c10, wx), lerp3(c01, c11, wx), wy);
+}
+
+// ---- kernel: RK main over the triangle scene ---------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
+    __shared__ uint32_t stacks[2 * kStack * 64 * WAVES];
+    uint32_t* tstack = stacks + threadIdx.x;
+    uint32_t* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
+    constexpr uint32_t stride = 64 * WAVES;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * (8u * WAVES) + wave * 8u + (lane & 7u);
+    const uint32_t row = lane >> 3;
+    const uint32_t y = (A.tile_first + blockIdx.y * A.tile_step) * 8u + row;
+    if (x >= A.W || y >= A.H) return;
+
+    const Scene sc = unpack_scene(A);
+    const v3 dir0 = primary_dir(A, sc, x, y);
+    uint32_t nrays = 0;
+    float dummy = 0.0f;
+    float dist = 0.0f;
+    v3 color = V(1.0f, 1.0f, 1.0f);
+    v3 ro = sc.cameraPos, rd = dir0;
+    float affect = 1.0f, sum = 0.0f;
+    for (uint32_t bounce = 0; bounce < sc.bounces; ++bounce) {                       // RK:113
+        const TriHit h = trace_tlas<false>(T, ro, rd, tstack, bstack, stride, dummy); // RK:114
+        ++nrays;
+        const bool hit = h.tri >= 0;
+        if (bounce == 0) dist = hit ? h.t : 0.0f;                                    // RK:116-118
+        const float next = affect + sum;                                             // RK:120
+        if (!hit) {                                                                  // RK:122-126
+            const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
+            color = divs(add(scale(sum, color), scale(affect, sky)), next);
+            break;
+        }
+        const Surface s = finish_hit(T, h);
+        ro = add(ro, scale(h.t, rd));                                                // RK:129
+        rd = normalize(reflect(rd, s.normal));                                       // RK:130
+        // RK:146-166
+        const v3 sdir = normalize(sub(ro, sc.lightPos));
+        const float distance = length(sdir);
+        const TriHit sh = trace_tlas<false>(T, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
+        ++nrays;
+        const float intensity = light_term(sc, ro, s.normal, sdir, distance, sh.tri >= 0, sh.t);
+        const v3 diffuseColor = scale(s.w, s.rgb);                                   // RK:133
+        const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));        // RK:134
+        const v3 blended = scale(intensity, add(diffuseColor, samplerColor));        // RK:135
+        color = divs(add(scale(sum, color), scale(affect, blended)), next);          // RK:136
+        affect = affect / 2.0f;                                                      // RK:139
+        sum = next;                                                                  // RK:140
+    }
+    const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;
+    reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, dir0, color, dist);   // RK:91-98
+    count_rays(A.rays, nrays);
+}
+
+// ---- kernel: the heatmap twin (HK:63-83) ------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArgs A, const RtTriScene T) {
+    __shared__ uint32_t stacks[2 * kStack * 64 * WAVES];
+    uint32_t* tstack = stacks + threadIdx.x;
+    uint32_t* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
+    constexpr uint32_t stride = 64 * WAVES;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * (8u * WAVES) + wave * 8u + (lane & 7u);
+    const uint32_t row = lane >> 3;
+    const uint32_t y = (A.tile_first + blockIdx.y * A.tile_step) * 8u + row;
+    if (x >= A.W || y >= A.H) return;
+    const Scene sc = unpack_scene(A);
+    const v3 dir0 = primary_dir(A, sc, x, y);                                        // HK:66-76
+    float traces = 0.0f;
+    (void)trace_tlas<true>(T, sc.cameraPos, dir0, tstack, bstack, stride, traces);   // HK:96-99, one bounce
+    const float g = clampf(traces / 300.0f, 0.0f, 1.0f);                             // HK:79
+    const uint32_t q = unorm8(g * 1.0f);                                             // HK:81-82
+    const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;
+    reinterpret_cast<uint32_t*>(A.out)[opix] = q | (q << 8) | (q << 16) | 0xFF000000u;
+    count_rays(A.rays, 1u);
+}
+
+}  // namespace rtk
+
+hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
+    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    constexpr int WAVES = 4;
+    dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
+    if (heatmap) hipLaunchKernelGGL(rtk::heatmap_triangles<WAVES>, grid, dim3(64 * WAVES), 0, s, a, t);
+    else         hipLaunchKernelGGL(rtk::trace_triangles<WAVES>, grid, dim3(64 * WAVES), 0, s, a, t);
+    return hipGetLastError();
+}

@@ -28,17 +28,19 @@ class RendererRaytracing:
         self.maxBounces = maxBounces
         self.rank, self.world = int(rank), int(world)
         self.skyboxMaterial = None             # RR:33
+        self.meshMaterial = None               # RR:32 mouseyMaterial (the mesh texture, binding 8)
         self.loaded = False                    # RR:51
         self.render_time_ms = None             # the 'render-time' label of RR:468-469
         self._ctx = None
         self._lib = None
 
     # ---- RR:62-68 -------------------------------------------------------------------------
-    def initialize(self, skybox=None):
+    def initialize(self, skybox=None, meshMaterial=None):
         self._lib = abi.load()
         ctx = ctypes.c_void_p()
         abi.check(self._lib.rt_create(self.device, ctypes.byref(ctx)))           # RR:78-97 setupDevice
         self._ctx = ctx
+        self.meshMaterial = meshMaterial
         self._create_assets(skybox)                                              # RR:99-153
         self.showRaytracer()                                                     # RR:356-365
         return self
@@ -69,11 +71,30 @@ class RendererRaytracing:
         L, c = self._lib, self._ctx
         p = self.scene.pack_params(self.maxBounces)                              # RR:157-165
         abi.check(L.rt_write_params(c, p.ctypes.data_as(ctypes.POINTER(ctypes.c_float))), c)
+        fp = ctypes.POINTER(ctypes.c_float)
+        if self.scene.triangles:                                                 # the reference's live scene type
+            b = np.ascontiguousarray(self.scene.pack_blas(), dtype=np.float32)           # RR:169-174
+            abi.check(L.rt_write_blas(c, b.ctypes.data_as(fp), b.shape[0]), c)
+            bl = np.ascontiguousarray(self.scene.pack_blas_lookup(), dtype=np.float32)   # RR:177-181
+            abi.check(L.rt_write_blas_lookup(c, bl.ctypes.data_as(fp), bl.shape[0]), c)
+            na = np.ascontiguousarray(self.scene.pack_tlas_nodes(), dtype=np.float32)    # RR:184-192
+            abi.check(L.rt_write_nodes(c, 0, na.ctypes.data_as(fp), na.shape[0]), c)
         if self.loaded:                                                          # RR:194-195
             return
         self.loaded = True
+        if self.scene.triangles:
+            t = np.ascontiguousarray(self.scene.pack_triangles(), dtype=np.float32)      # RR:198-209
+            abi.check(L.rt_write_triangles(c, t.ctypes.data_as(fp), t.shape[0]), c)
+            nb = np.ascontiguousarray(self.scene.pack_blas_nodes(), dtype=np.float32)    # RR:212-223
+            abi.check(L.rt_write_nodes(c, 32 * self.scene.tlasNodesMax, nb.ctypes.data_as(fp), nb.shape[0]), c)
+            tl = np.ascontiguousarray(self.scene.pack_tri_lookup(), dtype=np.float32)    # RR:225-229
+            abi.check(L.rt_write_tri_lookup(c, tl.ctypes.data_as(fp), tl.shape[0]), c)
+            if self.meshMaterial is not None:                                            # RR:113-114 mouseyMaterial
+                img = np.ascontiguousarray(self.meshMaterial.image, dtype=np.uint8)
+                abi.check(L.rt_write_mesh_texture(c, img.shape[1], img.shape[0], img.ctypes.data), c)
+            return
         s = np.ascontiguousarray(self.scene.pack_spheres(), dtype=np.float32)    # in place of RR:198-229
-        abi.check(L.rt_write_spheres(c, s.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), s.shape[0]), c)
+        abi.check(L.rt_write_spheres(c, s.ctypes.data_as(fp), s.shape[0]), c)
 
     # ---- RR:434-470 -----------------------------------------------------------------------
     def render(self):

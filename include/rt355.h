@@ -42,14 +42,14 @@ typedef enum rt_status {
     RT_ERR_INVALID_ARG = -1,  /* null pointer, bad size, bad enum                      */
     RT_ERR_NO_DEVICE = -2,    /* no gfx950 device / ordinal out of range                */
     RT_ERR_HIP = -3,          /* a HIP runtime call failed (message has the hipError)   */
-    RT_ERR_UNSUPPORTED = -4,  /* entry point declared for the boundary, not built yet   */
+    RT_ERR_UNSUPPORTED = -4,  /* combination not supported (e.g. heatmap of a sphere scene) */
     RT_ERR_STATE = -5,        /* call order: e.g. render before resize / write_params   */
     RT_ERR_CAPACITY = -6      /* destination buffer too small                           */
 } rt_status;
 
 typedef enum rt_kernel {
     RT_KERNEL_RAYTRACER = 0,  /* RR:70-72 showRaytracer()  */
-    RT_KERNEL_HEATMAP = 1     /* RR:74-76 showHeatmap()    (unsupported) */
+    RT_KERNEL_HEATMAP = 1     /* RR:74-76 showHeatmap(): traversal-cost visualiser, triangle scenes only */
 } rt_kernel;
 
 /* Arithmetic mode of the ray-trace kernel.
@@ -108,8 +108,13 @@ int rt_write_spheres(rt_ctx* ctx, const float* records, uint32_t n);
  * 0 +X, 1 -X, 2 +Y, 3 -Y, 4 +Z, 5 -Z; rgba8unorm, w*h*4 bytes, row 0 = top. */
 int rt_write_cubemap_face(rt_ctx* ctx, int face, uint32_t w, uint32_t h, const uint8_t* rgba);
 
-/* Triangle / BVH path of the reference.  Declared so that the boundary
- * is complete; return RT_ERR_UNSUPPORTED until that row is built. */
+/* The reference's live scene type: triangles behind a two-level BVH (RK:168-410).  Same byte
+ * layouts as RR writes: 160-B triangles (RR:198-209), 32-B nodes {min.xyz, leftChildIndex,
+ * max.xyz, primitiveCount} (indices and counts as f32), 80-B BLAS records {inverseModel
+ * column-major, rootNodeIndex, pad}, f32 lookup tables.  rt_write_nodes takes a byte offset like
+ * queue.writeBuffer(nodeBuffer, offset, ...): the TLAS nodes are rewritten every frame at offset
+ * 0 (RR:184-192), the BLAS nodes once at 32*tlasNodesMax (RR:212-223).  Writing triangles or
+ * nodes switches the context to the triangle scene; rt_write_spheres switches back. */
 int rt_write_triangles(rt_ctx* ctx, const float* data, uint32_t n_triangles);        /* RR:198-209 */
 int rt_write_nodes(rt_ctx* ctx, size_t byte_offset, const float* data, uint32_t n);  /* RR:184-192, 212-223 */
 int rt_write_blas(rt_ctx* ctx, const float* data, uint32_t n_blas);                  /* RR:169-174 */

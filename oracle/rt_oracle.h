@@ -99,6 +99,34 @@ void rt_oracle_pixel(const float params[24], const float* spheres, uint32_t n,
                      const rt_oracle_face faces[6], uint32_t W, uint32_t H, uint32_t x, uint32_t y,
                      float rgb[3], uint64_t* rays);
 
+/* ---- the reference's live triangle scene (RK:168-410): buffers exactly as RR:169-229 packs them */
+typedef struct {
+    const float* triangles;   uint32_t n_triangles;    /* 40 f32 each: per corner {pos.xyz,_, nrm.xyz,_, uv.xy,_,_}, colour vec4 @36 (RR:198-209) */
+    const float* nodes;       uint32_t n_nodes;        /* 8 f32 each: min.xyz, leftChildIndex, max.xyz, primitiveCount (RR:184-192, 212-223) */
+    const float* blas;        uint32_t n_blas;         /* 20 f32 each: inverseModel column-major, rootNodeIndex, 3 pad (RR:169-174) */
+    const float* tri_lookup;  uint32_t n_tri_lookup;   /* f32 indices (RR:225-229) */
+    const float* blas_lookup; uint32_t n_blas_lookup;  /* f32 indices (RR:177-181) */
+    rt_oracle_face mesh_tex;                            /* meshTex rgba8unorm (material.ts:61-65) */
+} rt_oracle_tri_scene;
+
+/* RK:73-166 over the triangle scene; arguments as rt_oracle_render_ex. */
+int rt_oracle_render_tri(const float params[24], const rt_oracle_tri_scene* tri,
+                         const rt_oracle_face faces[6], uint32_t W, uint32_t H,
+                         uint32_t tile_first, uint32_t tile_step,
+                         uint8_t* out_rgba8, float* out_rgb, uint16_t* out_rays_px,
+                         uint64_t* rays_out, int threads);
+void rt_oracle_pixel_tri(const float params[24], const rt_oracle_tri_scene* tri,
+                         const rt_oracle_face faces[6], uint32_t W, uint32_t H, uint32_t x, uint32_t y,
+                         float rgb[3], uint64_t* rays);
+
+/* HK:63-83, the heatmap kernel: out_steps (may be NULL) receives the raw `traces` count. */
+int rt_oracle_heatmap_tri(const float params[24], const rt_oracle_tri_scene* tri, uint32_t W, uint32_t H,
+                          uint8_t* out_rgba8, uint32_t* out_steps, int threads);
+
+/* Nearest hit (RK:168-244) of n arbitrary rays: out_t[i] = t, or -1 when nothing is hit. */
+int rt_oracle_trace_tri_rays(const rt_oracle_tri_scene* tri, uint32_t n, const float* origins,
+                             const float* dirs, float* out_t, int32_t* out_tri);
+
 int rt_oracle_max_threads(void);
 
 #ifdef __cplusplus

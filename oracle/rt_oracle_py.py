@@ -15,6 +15,15 @@ class _Face(ctypes.Structure):
     _fields_ = [("w", ctypes.c_uint32), ("h", ctypes.c_uint32), ("rgba", ctypes.c_void_p)]
 
 
+class _TriScene(ctypes.Structure):
+    _fields_ = [("triangles", ctypes.c_void_p), ("n_triangles", ctypes.c_uint32),
+                ("nodes", ctypes.c_void_p), ("n_nodes", ctypes.c_uint32),
+                ("blas", ctypes.c_void_p), ("n_blas", ctypes.c_uint32),
+                ("tri_lookup", ctypes.c_void_p), ("n_tri_lookup", ctypes.c_uint32),
+                ("blas_lookup", ctypes.c_void_p), ("n_blas_lookup", ctypes.c_uint32),
+                ("mesh_tex", _Face)]
+
+
 class _Hit(ctypes.Structure):
     _fields_ = [("t", ctypes.c_float), ("normal", ctypes.c_float * 3), ("hit", ctypes.c_int)]
 
@@ -54,6 +63,13 @@ def lib():
         L.rt_oracle_pixel.restype = None
         L.rt_oracle_pixel.argtypes = [fp, fp, ctypes.c_uint32, ctypes.POINTER(_Face), ctypes.c_uint32, ctypes.c_uint32,
                                       ctypes.c_uint32, ctypes.c_uint32, fp, ctypes.POINTER(ctypes.c_uint64)]
+        L.rt_oracle_render_tri.restype = ctypes.c_int
+        L.rt_oracle_render_tri.argtypes = [fp, ctypes.POINTER(_TriScene), ctypes.POINTER(_Face), ctypes.c_uint32,
+                                           ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+        L.rt_oracle_heatmap_tri.restype = ctypes.c_int
+        L.rt_oracle_heatmap_tri.argtypes = [fp, ctypes.POINTER(_TriScene), ctypes.c_uint32, ctypes.c_uint32,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.rt_oracle_max_threads.restype = ctypes.c_int
         _LIB = L
     return _LIB
@@ -151,6 +167,66 @@ def pixel(params, spheres, faces, W, H, x, y):
     rays = ctypes.c_uint64(0)
     lib().rt_oracle_pixel(_fp(params), _fp(spheres), spheres.shape[0], arr, W, H, x, y, _fp(out), ctypes.byref(rays))
     return out, rays.value
+
+
+def _tri_scene(buffers):
+    """buffers: dict with 'triangles' (n,40), 'nodes' (n,8), 'blas' (n,20), 'tri_lookup', 'blas_lookup'
+    float32 arrays in the layouts of RR:169-229 and 'mesh_tex' (h,w,4) uint8."""
+    keep = {k: np.ascontiguousarray(buffers[k], dtype=np.float32) for k in
+            ("triangles", "nodes", "blas", "tri_lookup", "blas_lookup")}
+    tex = np.ascontiguousarray(buffers["mesh_tex"], dtype=np.uint8)
+    keep["mesh_tex"] = tex
+    t = _TriScene()
+    t.triangles, t.n_triangles = keep["triangles"].ctypes.data, keep["triangles"].size // 40
+    t.nodes, t.n_nodes = keep["nodes"].ctypes.data, keep["nodes"].size // 8
+    t.blas, t.n_blas = keep["blas"].ctypes.data, keep["blas"].size // 20
+    t.tri_lookup, t.n_tri_lookup = keep["tri_lookup"].ctypes.data, keep["tri_lookup"].size
+    t.blas_lookup, t.n_blas_lookup = keep["blas_lookup"].ctypes.data, keep["blas_lookup"].size
+    t.mesh_tex.w, t.mesh_tex.h, t.mesh_tex.rgba = tex.shape[1], tex.shape[0], tex.ctypes.data
+    return t, keep
+
+
+def render_tri(params, buffers, faces, W, H, tile_first=0, tile_step=1, want_float=False, threads=0):
+    """RK:73-166 over a triangle scene.  Returns (rgba8, rgb float or None, rays)."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    t, keep = _tri_scene(buffers)
+    arr, keepf = _faces(faces)
+    out = np.zeros((H, W, 4), dtype=np.uint8)
+    outf = np.zeros((H, W, 3), dtype=np.float32) if want_float else None
+    rays = ctypes.c_uint64(0)
+    rc = lib().rt_oracle_render_tri(_fp(params), ctypes.byref(t), arr, W, H, tile_first, tile_step, out.ctypes.data,
+                                    outf.ctypes.data if want_float else None, None, ctypes.byref(rays), threads)
+    if rc != 0:
+        raise RuntimeError("rt_oracle_render_tri failed: %d" % rc)
+    return out, outf, rays.value
+
+
+def heatmap_tri(params, buffers, W, H, threads=0):
+    """HK:63-83.  Returns (rgba8 (H,W,4), raw traversal counts (H,W) uint32)."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    t, keep = _tri_scene(buffers)
+    out = np.zeros((H, W, 4), dtype=np.uint8)
+    steps = np.zeros((H, W), dtype=np.uint32)
+    rc = lib().rt_oracle_heatmap_tri(_fp(params), ctypes.byref(t), W, H, out.ctypes.data, steps.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError("rt_oracle_heatmap_tri failed: %d" % rc)
+    return out, steps
+
+
+def trace_tri_rays(buffers, origins, dirs):
+    """Nearest-hit t (or -1) of arbitrary rays against a triangle scene (RK:168-244)."""
+    t, keep = _tri_scene(buffers)
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(o.shape[0], dtype=np.float32)
+    L = lib()
+    L.rt_oracle_trace_tri_rays.restype = ctypes.c_int
+    L.rt_oracle_trace_tri_rays.argtypes = [ctypes.POINTER(_TriScene), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.rt_oracle_trace_tri_rays(ctypes.byref(t), o.shape[0], o.ctypes.data, d.ctypes.data, out.ctypes.data, None)
+    if rc != 0:
+        raise RuntimeError("rt_oracle_trace_tri_rays failed")
+    return out
 
 
 def max_threads():

@@ -54,15 +54,15 @@ def test_null_arguments_are_rejected():
     assert b"NULL" in lib.rt_last_error(None)
 
 
-def test_triangle_path_reports_unsupported():
+def test_triangle_entry_points_check_arguments():
     lib = abi.load()
-    assert lib.rt_write_triangles(None, None, 0) == abi.RT_ERR_UNSUPPORTED
-    assert lib.rt_write_nodes(None, 0, None, 0) == abi.RT_ERR_UNSUPPORTED
-    assert lib.rt_write_blas(None, None, 0) == abi.RT_ERR_UNSUPPORTED
-    assert lib.rt_write_tri_lookup(None, None, 0) == abi.RT_ERR_UNSUPPORTED
-    assert lib.rt_write_blas_lookup(None, None, 0) == abi.RT_ERR_UNSUPPORTED
-    assert lib.rt_write_mesh_texture(None, 0, 0, None) == abi.RT_ERR_UNSUPPORTED
-    assert b"8(f)" in lib.rt_last_error(None)
+    assert lib.rt_write_triangles(None, None, 0) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_write_nodes(None, 0, None, 0) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_write_blas(None, None, 0) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_write_tri_lookup(None, None, 0) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_write_blas_lookup(None, None, 0) == abi.RT_ERR_INVALID_ARG
+    assert lib.rt_write_mesh_texture(None, 0, 0, None) == abi.RT_ERR_INVALID_ARG
+    assert b"NULL" in lib.rt_last_error(None)
 
 
 @pytest.mark.parametrize("H", [1, 7, 8, 9, 256, 1080, 2160, 4320, 53])

@@ -221,7 +221,8 @@ def test_call_order_and_capacity_errors():
         abi.check(L.rt_write_spheres(ctx, None, 0), ctx)
         assert L.rt_render(ctx) == abi.RT_ERR_STATE and b"cube map" in L.rt_last_error(ctx)
         assert L.rt_write_cubemap_face(ctx, 6, 1, 1, p.ctypes.data) == abi.RT_ERR_INVALID_ARG
-        assert L.rt_select_kernel(ctx, abi.RT_KERNEL_HEATMAP) == abi.RT_ERR_UNSUPPORTED
+        assert L.rt_select_kernel(ctx, abi.RT_KERNEL_HEATMAP) == abi.RT_OK
+        assert L.rt_select_kernel(ctx, abi.RT_KERNEL_RAYTRACER) == abi.RT_OK
         assert L.rt_select_kernel(ctx, 7) == abi.RT_ERR_INVALID_ARG
         assert L.rt_set_partition(ctx, 2, 2) == abi.RT_ERR_INVALID_ARG
         assert L.rt_set_mode(ctx, 5) == abi.RT_ERR_INVALID_ARG
