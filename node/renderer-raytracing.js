@@ -31,7 +31,8 @@ class RendererRaytracing {
     this.ctx = null;
   }
 
-  async initialize(skybox) {                                         // RR:62-68
+  async initialize(skybox, meshTexture) {                            // RR:62-68
+    this.meshTexture = meshTexture || null;                          // {width, height, data: Uint8Array}
     const rt = loadAddon();
     this.ctx = rt.create(this.device);                               // RR:78-97 setupDevice
     this.skyboxMaterial = skybox || CubemapMaterial.constant(CONSTANT_SKY_RGBA);   // RR:100-101
@@ -55,8 +56,58 @@ class RendererRaytracing {
     sceneParametersData.set(this.scene.light.position, 16);
     sceneParametersData.set([this.scene.light.lightIntensity, this.scene.light.minIntensity, this.maxBounces], 19);
     rt.writeParams(this.ctx, sceneParametersData);                   // RR:165
+    const tri = this.scene.triangles && this.scene.triangles.length > 0;   // the reference's live scene type
+    if (tri) {
+      const blasData = new Float32Array(20 * this.scene.blasList.length);           // RR:169-174
+      for (let i = 0; i < this.scene.blasList.length; ++i) {
+        blasData.set(this.scene.blasList[i].inverseModel, 20 * i);
+        blasData.set([this.scene.blasList[i].rootNodeIndex], 20 * i + 16);
+      }
+      rt.writeBlas(this.ctx, blasData);
+      const blasIndexData = new Float32Array(this.scene.blasIndices.length);        // RR:177-181
+      for (let i = 0; i < this.scene.blasIndices.length; ++i) blasIndexData[i] = this.scene.blasIndices[i];
+      rt.writeBlasLookup(this.ctx, blasIndexData);
+      const nodeDataA = new Float32Array(8 * this.scene.tlasNodesUsed);             // RR:184-192
+      for (let i = 0; i < this.scene.tlasNodesUsed; ++i) {
+        const loc = 8 * i;
+        nodeDataA.set(this.scene.nodes[i].minCorner, loc);
+        nodeDataA.set(this.scene.nodes[i].maxCorner, loc + 4);
+        nodeDataA[loc + 3] = this.scene.nodes[i].leftChildIndex;
+        nodeDataA[loc + 7] = this.scene.nodes[i].primitiveCount;
+      }
+      rt.writeNodes(this.ctx, 0, nodeDataA);
+    }
     if (this.loaded) return;                                         // RR:194-195
     this.loaded = true;
+    if (tri) {
+      const triangleData = new Float32Array(40 * this.scene.triangles.length);      // RR:198-209
+      for (let i = 0; i < this.scene.triangles.length; i++) {
+        const loc = 40 * i;
+        const t = this.scene.triangles[i];
+        for (let corner = 0; corner < 3; corner++) {
+          triangleData.set(t.corners[corner], loc + 12 * corner);
+          triangleData.set(t.normals[corner], loc + 12 * corner + 4);
+          triangleData.set(t.textures[corner], loc + 12 * corner + 8);
+        }
+        triangleData.set(t.color, loc + 36);
+      }
+      rt.writeTriangles(this.ctx, triangleData);
+      const nodeDataB = new Float32Array(8 * this.scene.blasNodesUsed);             // RR:212-223
+      for (let i = 0; i < this.scene.blasNodesUsed; ++i) {
+        const node = this.scene.nodes[this.scene.tlasNodesMax + i];
+        const loc = 8 * i;
+        nodeDataB.set(node.minCorner, loc + 0);
+        nodeDataB.set([node.leftChildIndex], loc + 3);
+        nodeDataB.set(node.maxCorner, loc + 4);
+        nodeDataB.set([node.primitiveCount], loc + 7);
+      }
+      rt.writeNodes(this.ctx, 32 * this.scene.tlasNodesMax, nodeDataB);
+      const triangleIndexData = new Float32Array(this.scene.triangleIndices.length);   // RR:225-229
+      for (let i = 0; i < this.scene.triangleIndices.length; ++i) triangleIndexData[i] = this.scene.triangleIndices[i];
+      rt.writeTriLookup(this.ctx, triangleIndexData);
+      if (this.meshTexture) rt.writeMeshTexture(this.ctx, this.meshTexture.width, this.meshTexture.height, this.meshTexture.data);   // RR:113-114
+      return;
+    }
     const spheres = this.scene.spheres;                              // in place of RR:198-229
     const data = new Float32Array(8 * spheres.length);
     for (let i = 0; i < spheres.length; ++i) {

@@ -161,6 +161,49 @@ static napi_value WriteCubemapFace(napi_env env, napi_callback_info info) {
     return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
 }
 
+/* the reference's triangle scene, same byte layouts as RR:169-229 */
+#define F32_UPLOAD(NAME, CALL, STRIDE, WHAT)                                                     \
+    static napi_value NAME(napi_env env, napi_callback_info info) {                              \
+        napi_value argv[2];                                                                      \
+        void* data; size_t len;                                                                  \
+        if (!get_args(env, info, 2, argv)) return NULL;                                          \
+        rt_ctx* ctx = get_ctx(env, argv[0]);                                                     \
+        if (!ctx || !get_typed(env, argv[1], napi_float32_array, &data, &len)) return NULL;      \
+        if (len % (STRIDE)) { napi_throw_range_error(env, NULL, "rt355: " WHAT); return NULL; }  \
+        int rc = CALL(ctx, (const float*)data, (uint32_t)(len / (STRIDE)));                      \
+        return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);                        \
+    }
+F32_UPLOAD(WriteTriangles, rt_write_triangles, 40, "triangles are 40 floats each (RR:198-209)")
+F32_UPLOAD(WriteBlas, rt_write_blas, 20, "BLAS records are 20 floats each (RR:169-174)")
+F32_UPLOAD(WriteTriLookup, rt_write_tri_lookup, 1, "")
+F32_UPLOAD(WriteBlasLookup, rt_write_blas_lookup, 1, "")
+
+static napi_value WriteNodes(napi_env env, napi_callback_info info) {   /* (ctx, byteOffset, Float32Array) */
+    napi_value argv[3];
+    uint32_t off;
+    void* data; size_t len;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_u32(env, argv[1], &off) || !get_typed(env, argv[2], napi_float32_array, &data, &len)) return NULL;
+    if (len % 8) { napi_throw_range_error(env, NULL, "rt355: nodes are 8 floats each (RR:184-192)"); return NULL; }
+    int rc = rt_write_nodes(ctx, off, (const float*)data, (uint32_t)(len / 8));
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value WriteMeshTexture(napi_env env, napi_callback_info info) {   /* (ctx, w, h, Uint8Array) */
+    napi_value argv[4];
+    uint32_t w, h;
+    void* data; size_t len;
+    if (!get_args(env, info, 4, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_u32(env, argv[1], &w) || !get_u32(env, argv[2], &h) ||
+        !get_typed(env, argv[3], napi_uint8_array, &data, &len))
+        return NULL;
+    if (len != (size_t)w * h * 4) { napi_throw_range_error(env, NULL, "rt355: texture needs w*h*4 bytes"); return NULL; }
+    int rc = rt_write_mesh_texture(ctx, w, h, (const uint8_t*)data);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
 #define INT_SETTER(NAME, CALL)                                                 \
     static napi_value NAME(napi_env env, napi_callback_info info) {            \
         napi_value argv[2];                                                    \
@@ -299,6 +342,8 @@ static napi_value Init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"create", Create}, {"destroy", Destroy}, {"resize", Resize}, {"writeParams", WriteParams},
         {"writeSpheres", WriteSpheres}, {"writeCubemapFace", WriteCubemapFace}, {"selectKernel", SelectKernel},
+        {"writeTriangles", WriteTriangles}, {"writeNodes", WriteNodes}, {"writeBlas", WriteBlas},
+        {"writeTriLookup", WriteTriLookup}, {"writeBlasLookup", WriteBlasLookup}, {"writeMeshTexture", WriteMeshTexture},
         {"setMode", SetMode}, {"setVariant", SetVariant}, {"setPartition", SetPartition}, {"render", Render},
         {"wait", Wait}, {"waitSync", WaitSync}, {"readPixels", ReadPixels}, {"stats", Stats},
         {"abiVersion", AbiVersion},

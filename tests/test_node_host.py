@@ -79,3 +79,49 @@ def test_node_renders_baseline_config(tmp_path, name, mode):
     assert res["sha256"] == fr["sha256"] and res["rays"] == fr["rays"] and res["frames"] == 2
     data = open(raw, "rb").read()
     assert len(data) == fr["width"] * fr["height"] * 4 and hashlib.sha256(data).hexdigest() == fr["sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heatmap", [False, True])
+def test_node_renders_triangle_scene(tmp_path, oracle, heatmap):
+    """A triangle scene handed to the JS RendererRaytracing as an object of the reference's
+    SceneRaytracing shape: packing in JS (RR:169-229) -> N-API -> C ABI -> HIP; frame hash against
+    the oracle's frame for the same buffers."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import tri_buffers, triangle_scene
+    from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
+    scene, mat = triangle_scene(seed=17, n_models=2, rings=5, sectors=6)
+    W, H, B = 160, 96, 3
+    f = lambda a: [float(v) for v in a]
+    js = {
+        "camera": {"position": f(scene.camera.position), "forwards": f(scene.camera.forwards),
+                   "right": f(scene.camera.right), "up": f(scene.camera.up)},
+        "light": {"position": f(scene.light.position), "lightIntensity": scene.light.lightIntensity,
+                  "minIntensity": scene.light.minIntensity},
+        "triangles": [{"corners": [f(c) for c in t.corners], "normals": [f(c) for c in t.normals],
+                       "textures": [f(c) for c in t.textures], "color": f(t.color)} for t in scene.triangles],
+        "nodes": [{"minCorner": f(n.minCorner), "maxCorner": f(n.maxCorner), "leftChildIndex": n.leftChildIndex,
+                   "primitiveCount": n.primitiveCount} if n is not None else
+                  {"minCorner": [0, 0, 0], "maxCorner": [0, 0, 0], "leftChildIndex": 0, "primitiveCount": 0}
+                  for n in scene.nodes],
+        "blasList": [{"inverseModel": f(b.inverseModel), "rootNodeIndex": b.rootNodeIndex} for b in scene.blasList],
+        "blasIndices": list(scene.blasIndices), "triangleIndices": list(scene.triangleIndices),
+        "tlasNodesUsed": scene.tlasNodesUsed, "tlasNodesMax": scene.tlasNodesMax, "blasNodesUsed": scene.blasNodesUsed,
+    }
+    doc = {"width": W, "height": H, "bounces": B, "scene": js,
+           "meshTexture": {"width": mat.image.shape[1], "height": mat.image.shape[0], "data": mat.image.reshape(-1).tolist()}}
+    path = str(tmp_path / "scene.json")
+    json.dump(doc, open(path, "w"))
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "render-json-scene.js"), path, str(tmp_path / "o.rgba")] +
+                         (["heatmap"] if heatmap else []), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    b = tri_buffers(scene, mat)
+    if heatmap:
+        ref, _ = oracle.heatmap_tri(scene.pack_params(B), b, W, H)
+    else:
+        sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+        ref, _, rays = oracle.render_tri(scene.pack_params(B), b, sky.faces, W, H)
+        assert res["rays"] == rays
+    assert res["sha256"] == hashlib.sha256(ref.tobytes()).hexdigest()
