@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N>1 code path (render_to + all-gather + assemble) even with one rank; "
+                         "used by tests/test_bench_gpu.py to exercise that path on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -95,16 +98,23 @@ def main():
         sys.exit("bench.py: no GPU visible; the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or a.force_dist
+    if multi:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:          # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"),
+                              RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     name = a.config or ("C3" if world == 1 else "C4")
+    if name not in rt.BASELINE_CONFIGS:
+        sys.exit("bench.py: unknown config %s" % name)
     cfg = rt.BASELINE_CONFIGS[name]
     W, H, N, B = cfg["width"], cfg["height"], cfg["spheres"], cfg["bounces"]
     scene = rt.synthetic_scene(N, cfg["seed"])
     if cfg["skybox"]:
-        sky = rt.CubemapMaterial.from_png(os.path.join(ROOT, "assets", "daylight-skybox.png"))
+        png = os.path.join(ROOT, "assets", "daylight-skybox.png")    # the reference's asset, if the user supplies it
+        sky = rt.CubemapMaterial.from_png(png) if os.path.exists(png) else rt.CubemapMaterial.synthetic_daylight()
     else:
         sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
 
@@ -115,14 +125,14 @@ def main():
     r.recalculateScene()   # uploads: scene resident in HBM before anything is timed
 
     stream = torch.cuda.current_stream()
-    if world > 1:
+    if multi:
         msg = tiles.message_bytes(W, H, world)
         local = torch.zeros(msg, dtype=torch.uint8, device="cuda")
         gathered = torch.empty(world * msg, dtype=torch.uint8, device="cuda")
         frame = torch.empty(H * W * 4, dtype=torch.uint8, device="cuda")
 
     def step():
-        if world == 1:
+        if not multi:
             r.enqueue()                       # prep + ray-trace kernel on the context's stream
         else:
             sp = stream.cuda_stream
@@ -131,7 +141,7 @@ def main():
             r.assemble_frame(gathered.data_ptr(), frame.data_ptr(), world, sp)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,7 +170,7 @@ def main():
     kernel_frames += st["batch_frames"]
     rays_local = st["rays"]
 
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed, float(rays_local), kernel_ms_sum / max(kernel_frames, 1)],
                          dtype=torch.float64, device="cuda")
         tmax = t.clone()
@@ -217,8 +227,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, scene, sky, a.cpu_seconds)
         print(json.dumps(out), flush=True)
 
+    if multi and rank == 0 and os.environ.get("RT355_BENCH_CHECK_FRAME"):
+        # test hook: hash of the assembled frame, to compare with the single-kernel path
+        import hashlib
+        torch.cuda.synchronize()
+        print("frame_sha256 " + hashlib.sha256(frame.cpu().numpy().tobytes()).hexdigest(), file=sys.stderr, flush=True)
     r.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,53 @@
+"""bench.py and __graft_entry__.smoke() on the GPU box: the JSON contract, and the N>1 code path
+(rt_render_to on torch's stream -> all_gather_into_tensor over RCCL -> rt_assemble_frame) taken
+with a single rank, its assembled frame hashed against the oracle's golden frame."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), cwd=ROOT, env=e,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line), out.stderr
+
+
+def test_bench_json_contract():
+    d, _ = run_bench("--steps", "3", "--warmup", "1", "--config", "C2", "--cpu-seconds", "2")
+    for k in ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]:
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["config"]["rays_per_frame"] == 9061272                      # C2, the oracle's count
+    r = d["roofline"]
+    assert r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["hbm"]["bytes_per_launch"] == 4 * 1920 * 1080 + 32 * 64 + 96
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "tiles" in c["sample"]
+    assert abs(d["value"] - d["config"]["rays_per_frame"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
+
+
+def test_bench_distributed_path_with_one_rank():
+    fr = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["C2"]
+    d, err = run_bench("--steps", "2", "--warmup", "1", "--config", "C2", "--no-cpu-baseline", "--force-dist",
+                       env={"RT355_BENCH_CHECK_FRAME": "1", "MASTER_PORT": "29541"})
+    sha = [l.split()[1] for l in err.splitlines() if l.startswith("frame_sha256")]
+    assert sha and sha[0] == fr["sha256"]
+    assert d["config"]["rays_per_frame"] == fr["rays"] and "cpu_baseline" not in d
+
+
+def test_smoke_entry_point():
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:]
