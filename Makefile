@@ -3,7 +3,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 CSRC     := compute_raytracer_amd/csrc
 LIB      := compute_raytracer_amd/librt355.so
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-fast-math -Wall -Wno-unused-function
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-fast-math -Wall -Wno-unused-function $(EXTRA)
 OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_triangles.o $(CSRC)/rt_assemble.o
 
 all: lib oracle node

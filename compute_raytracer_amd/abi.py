@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt355.so")
+LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_HERE, "librt355.so")   # RT355_LIB: A/B builds (tools/)
 
 RT_OK = 0
 RT_ERR_INVALID_ARG = -1
@@ -48,6 +48,27 @@ class RtError(RuntimeError):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A PyTorch-ROCm wheel bundles its own libamdhip64.so.7; librt355.so is linked against the
+    system one (/opt/rocm).  Both have the same SONAME, so whichever is loaded first serves the
+    whole process -- and torch does not find its GPUs on the system copy.  When torch is installed
+    but not imported yet, load ITS runtime first (without importing torch), so that a later
+    `import torch` (bench.py, the multi-GPU path) and this library share one HIP runtime."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Loads librt355.so (built by `make lib` / __graft_entry__.build()).  Raises if absent."""
     global _lib
@@ -55,6 +76,7 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RtError(RT_ERR_NO_DEVICE, "librt355.so is not built (%s); run `make lib`. There is no CPU path." % LIB_PATH)
+    _one_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t
     fp = ctypes.POINTER(ctypes.c_float)
