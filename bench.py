@@ -127,21 +127,33 @@ def main():
     stream = torch.cuda.current_stream()
     if multi:
         msg = tiles.message_bytes(W, H, world)
-        local = torch.zeros(msg, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(world * msg, dtype=torch.uint8, device="cuda")
+        # double-buffered: the all-gather of frame k (RCCL's stream) overlaps the render of frame k+1
+        local = [torch.zeros(msg, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        gathered = [torch.empty(world * msg, dtype=torch.uint8, device="cuda") for _ in range(2)]
         frame = torch.empty(H * W * 4, dtype=torch.uint8, device="cuda")
+    pending = []       # [(work, buffer index)] gathers whose frame is not assembled yet
+    counter = [0]
+
+    def finish_pending():
+        while pending:
+            work, k = pending.pop(0)
+            work.wait()                                               # current stream waits for the gather
+            r.assemble_frame(gathered[k].data_ptr(), frame.data_ptr(), world, stream.cuda_stream)
 
     def step():
         if not multi:
             r.enqueue()                       # prep + ray-trace kernel on the context's stream
         else:
-            sp = stream.cuda_stream
-            r.render_to(local.data_ptr(), local.numel(), sp)          # this rank's tiles
-            dist.all_gather_into_tensor(gathered, local)              # RCCL over xGMI
-            r.assemble_frame(gathered.data_ptr(), frame.data_ptr(), world, sp)
+            k = counter[0] & 1
+            counter[0] += 1
+            r.render_to(local[k].data_ptr(), local[k].numel(), stream.cuda_stream)   # this rank's tiles
+            work = dist.all_gather_into_tensor(gathered[k], local[k], async_op=True)  # RCCL over xGMI
+            finish_pending()                  # frame k-1: wait for its gather, de-interleave
+            pending.append((work, k))
 
     def fence():
         if multi:
+            finish_pending()                  # every step's frame is assembled inside the timed region
             dist.barrier()
         torch.cuda.synchronize()
 
