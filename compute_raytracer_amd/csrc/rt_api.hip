@@ -415,8 +415,6 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         const float* w = reinterpret_cast<const float*>(b + 7u * m);
         fa.geo_w = w; fa.lgt_w = w + m; fa.cam_w = w + 2u * m;
     }
-    if (!tri && (size_t)c->n16 * 2u * sizeof(float4) + 8u * 8u * 256u > 160u * 1024u)
-        return fail(RT_ERR_UNSUPPORTED, "rt_render: more than 4608 spheres need chunked LDS staging (not built yet)");
     {   // sign-aware filter only while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays
         // below half of the 0.001 a valid hit needs (rt_kernels.hip: filter_one)
         const float* p = c->params;

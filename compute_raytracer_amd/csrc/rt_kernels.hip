@@ -382,25 +382,28 @@ struct SceneLds {
 // W_LDS       : exact 4th components in LDS too (else read from global when a candidate is evaluated).
 //               In strict mode (no 4th-component arrays) the flag means "camera records in LDS":
 //               false keeps them in global memory so that 4096 spheres still fit.
-template <int WAVES, bool FILTER, bool FIRST, bool SGN, bool W_LDS, int CAP>
+// GS          : "global scene": nothing is staged, the records are read from global memory (L2)
+//               with wave-uniform addresses.  The fallback for scenes too large for a CU's LDS
+//               (> 4608 spheres); the per-wave candidate lists still live in LDS.
+template <int WAVES, bool FILTER, bool FIRST, bool SGN, bool W_LDS, int CAP, bool GS = false>
 __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t N = A.N, N16 = A.N16;
-    const uint32_t n = FILTER ? N16 : N;
+    const uint32_t n = GS ? 0u : (FILTER ? N16 : N);
     // float4 arrays first, then the float arrays, then the candidate lists
     constexpr bool CAM_LDS = FILTER || W_LDS;
-    float4* sL = lds;
-    float4* sC = lds + n;
-    float4* sG = lds + (CAM_LDS ? 2 : 1) * n;       // unused when FIRST
+    const float4* sL = GS ? (FILTER ? A.lgt_f : A.lgt) : lds;
+    const float4* sC = GS ? (FILTER ? A.cam_f : A.cam) : lds + n;
+    const float4* sG = GS ? (FILTER ? A.geo_f : A.geo) : lds + (CAM_LDS ? 2 : 1) * n;       // unused when FIRST
     float* wbase = reinterpret_cast<float*>(lds + (FIRST ? 2 : 3) * n);
     float* sLw = wbase;
     float* sCw = wbase + n;
     float* sGw = wbase + 2 * n;
     uint32_t* lists = reinterpret_cast<uint32_t*>(wbase + ((FILTER && W_LDS) ? (FIRST ? 2 : 3) * n : 0));
     for (uint32_t i = threadIdx.x; i < n; i += 64 * WAVES) {
-        sL[i] = FILTER ? A.lgt_f[i] : A.lgt[i];
-        if (CAM_LDS) sC[i] = FILTER ? A.cam_f[i] : A.cam[i];
-        if (!FIRST) sG[i] = FILTER ? A.geo_f[i] : A.geo[i];
+        lds[i] = FILTER ? A.lgt_f[i] : A.lgt[i];
+        if (CAM_LDS) lds[n + i] = FILTER ? A.cam_f[i] : A.cam[i];
+        if (!FIRST) lds[(CAM_LDS ? 2 : 1) * n + i] = FILTER ? A.geo_f[i] : A.geo[i];
         if (FILTER && W_LDS) {
             sLw[i] = A.lgt_w[i];
             sCw[i] = A.cam_w[i];
@@ -408,10 +411,10 @@ __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) 
         }
     }
     __syncthreads();
-    const float* Lw = (FILTER && W_LDS) ? sLw : A.lgt_w;
-    const float* Cw = (FILTER && W_LDS) ? sCw : A.cam_w;
-    const float* Gw = (FILTER && W_LDS) ? sGw : A.geo_w;
-    const float4* camE = CAM_LDS ? sC : A.cam;      // strict mode only
+    const float* Lw = (FILTER && W_LDS && !GS) ? sLw : A.lgt_w;
+    const float* Cw = (FILTER && W_LDS && !GS) ? sCw : A.cam_w;
+    const float* Gw = (FILTER && W_LDS && !GS) ? sGw : A.geo_w;
+    const float4* camE = (CAM_LDS || GS) ? sC : A.cam;      // strict mode only
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     CandList<CAP> cl;
@@ -790,12 +793,12 @@ size_t lds_pixels(const RtFrameArgs& a) {
     return n * arrays * 16u + ((FILTER && W_LDS) ? n * arrays * 4u : 0u) + (FILTER ? (size_t)WAVES * CAP * 256u : 0u);
 }
 
-template <int WAVES, bool FILTER, bool FIRST, bool SGN, bool W_LDS, int CAP>
+template <int WAVES, bool FILTER, bool FIRST, bool SGN, bool W_LDS, int CAP, bool GS = false>
 hipError_t launch_pixels(const RtFrameArgs& a, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
-    const size_t lds = lds_pixels<WAVES, FILTER, FIRST, W_LDS, CAP>(a);
+    const size_t lds = GS ? (FILTER ? (size_t)WAVES * CAP * 256u : 0u) : lds_pixels<WAVES, FILTER, FIRST, W_LDS, CAP>(a);
     if (lds > kLdsCap) return hipErrorInvalidValue;
-    auto k = trace_pixels<WAVES, FILTER, FIRST, SGN, W_LDS, CAP>;
+    auto k = trace_pixels<WAVES, FILTER, FIRST, SGN, W_LDS, CAP, GS>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
     dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
@@ -855,12 +858,14 @@ hipError_t launch_strict(const RtFrameArgs& a, hipStream_t s) {
     if (bytes <= 56u * 1024u) return launch_pixels<8, false, false, false, true, 1>(a, s);
     if (bytes <= kLdsCap)     return launch_pixels<16, false, false, false, true, 1>(a, s);
     if ((size_t)a.N * 32u <= kLdsCap) return launch_pixels<16, false, false, false, false, 1>(a, s);
-    return hipErrorInvalidValue;
+    return launch_pixels<4, false, false, false, false, 1, true>(a, s);      // any N: records from global memory
 }
 
 template <bool SGN>
 hipError_t launch_fast(const RtFrameArgs& a, int variant, hipStream_t s) {
     const size_t rec = (size_t)a.N16 * 16u;
+    if (2 * rec + 8u * 8u * 256u > kLdsCap)                                  // > 4608 spheres: no LDS staging
+        return launch_pixels<4, true, false, SGN, false, 16, true>(a, s);
     const bool small = 3 * rec + 3 * (rec / 4) + 8u * 16u * 256u <= 80u * 1024u;      // N <= ~800: 2 workgroups of 8 waves per CU
     const bool pipeline = a.queue && a.qctrl && a.N >= 128u;
     switch (variant) {

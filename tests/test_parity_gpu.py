@@ -134,6 +134,18 @@ def test_lds_stress_4096_spheres_with_textured_skybox(oracle):
         assert st["rays"] == rays and st["spheres"] == 4096
 
 
+def test_more_spheres_than_fit_in_lds(oracle):
+    """6000 spheres exceed a CU's 160 KiB of LDS (two 16-B records per sphere): the records are
+    then read from global memory instead of being staged."""
+    scene = rt.synthetic_scene(6000, 4242)
+    W, H, B = 160, 96, 3
+    ref, _, rays = oracle_render(oracle, scene, W, H, B)
+    for strict in (True, False):
+        img, st = gpu_render(scene, W, H, B, strict=strict)
+        assert np.array_equal(img, ref), diff_stats(img, ref)
+        assert st["rays"] == rays and st["spheres"] == 6000
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3])
 def test_kernel_variants_agree(oracle, variant):
     cfg, scene = config_inputs("C2", width=480, height=272)
