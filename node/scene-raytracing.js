@@ -4,6 +4,9 @@
 // generator as compute_raytracer_amd/scene_raytracing.py (SURVEY.md 8(d)); BigInt splitmix64.
 const { Camera } = require('./camera');
 const { Sphere } = require('./sphere');
+const { vec3 } = require('./gl-matrix-lite');
+const { Node } = require('./acceleration/node');
+const { BLAS } = require('./acceleration/blas');
 
 const M64 = (1n << 64n) - 1n;
 const BASELINE_CONFIGS = {
@@ -45,13 +48,131 @@ function syntheticSpheres(n, seed) {
 }
 
 class SceneRaytracing {
-  constructor() { this.camera = null; this.light = null; this.spheres = []; }
+  constructor() {
+    this.camera = null; this.light = null; this.spheres = [];
+    // triangle-scene members, scene-raytracing.ts:19-35
+    this.meshes = []; this.models = []; this.triangles = []; this.triangleIndices = [];
+    this.nodes = []; this.blasList = []; this.blasIndices = [];
+    this.tlasNodesMax = 0; this.tlasNodesUsed = 0; this.blasNodesUsed = 0; this.blasConsumed = false;
+  }
   async createScene(spheres) {                                       // scene-raytracing.ts:37-45
     this.camera = new Camera([0.0593, 2.692, 3.293], 106, 270);
     this.light = { position: [0, 5, 0], lightIntensity: 3.0, minIntensity: 0.3 };
     this.spheres = spheres || [];
     return this;
   }
-  update(dt) { return dt; }                                          // scene-raytracing.ts:138-143: static spheres
+  update(dt) {                                                       // scene-raytracing.ts:138-143
+    if (this.models.length) {
+      for (const model of this.models) model.update(dt);
+      this.buildBVH();
+    }
+  }
+
+  // ---- the reference's live scene type (scene-raytracing.ts:73-272), meshes/models from the caller
+  createTriangleScene(meshes, models) {
+    this.meshes = meshes;
+    this.triangles = [];                                             // SR:75-79
+    for (const mesh of this.meshes) {
+      mesh.triangleLookupOffset = this.triangles.length;
+      for (const t of mesh.triangles) this.triangles.push(t);
+    }
+    this.triangleIndices = new Array(this.triangles.length);         // SR:82-93
+    {
+      let i = 0, offset = 0;
+      for (const mesh of this.meshes) {
+        for (let j = 0; j < mesh.bvh.triangleIndices.length; ++j) { this.triangleIndices[i] = mesh.bvh.triangleIndices[j] + offset; ++i; }
+        offset += mesh.bvh.triangleIndices.length;
+      }
+    }
+    this.models = models;                                            // SR:96-111
+    this.tlasNodesMax = 2 * this.models.length - 1;                  // SR:114
+    this.blasNodesUsed = 0;                                          // SR:116-120
+    for (const mesh of this.meshes) { mesh.rootNodeIndex = this.tlasNodesMax + this.blasNodesUsed; this.blasNodesUsed += mesh.bvh.nodesUsed; }
+    this.nodes = new Array(this.tlasNodesMax + this.blasNodesUsed);  // SR:123-131
+    for (let i = 0; i < this.tlasNodesMax; i += 1) {
+      const node = new Node();
+      node.leftChildIndex = 0; node.primitiveCount = 0; node.minCorner = [0, 0, 0]; node.maxCorner = [0, 0, 0];
+      this.nodes[i] = node;
+    }
+    this.buildBVH();                                                 // SR:133
+    this.finalizeBVH();                                              // SR:134
+    this.blasConsumed = true;
+    return this;
+  }
+  buildBVH() {                                                       // SR:145-179
+    this.tlasNodesUsed = 0;
+    this.blasList = new Array(this.models.length);
+    this.blasIndices = new Array(this.models.length);
+    for (let i = 0; i < this.tlasNodesMax; ++i) {
+      this.nodes[i].leftChildIndex = 0; this.nodes[i].primitiveCount = 0;
+      this.nodes[i].minCorner = [0, 0, 0]; this.nodes[i].maxCorner = [0, 0, 0];
+    }
+    for (let i = 0; i < this.models.length; ++i) {
+      const model = this.models[i];
+      const mesh = this.meshes[model.meshIndex];
+      this.blasList[i] = new BLAS(mesh.rootNodeIndex, mesh.bvh.minCorner, mesh.bvh.maxCorner, model.model);
+      this.blasIndices[i] = i;
+    }
+    const root = this.nodes[0];
+    root.leftChildIndex = 0;
+    root.primitiveCount = this.blasList.length;
+    this.tlasNodesUsed += 1;
+    this.updateBounds(0);
+    this.subdivide(0);
+  }
+  updateBounds(nodeIndex) {                                          // SR:181-191
+    const node = this.nodes[nodeIndex];
+    node.minCorner = [1e30, 1e30, 1e30];
+    node.maxCorner = [-1e30, -1e30, -1e30];
+    for (let i = 0; i < node.primitiveCount; i += 1) {
+      const blas = this.blasList[this.blasIndices[node.leftChildIndex + i]];
+      vec3.min(node.minCorner, node.minCorner, blas.minCorner);
+      vec3.max(node.maxCorner, node.maxCorner, blas.maxCorner);
+    }
+  }
+  subdivide(nodeIndex) {                                             // SR:193-254
+    const node = this.nodes[nodeIndex];
+    if (node.primitiveCount < 2) return;
+    const extent = vec3.create();
+    vec3.subtract(extent, node.maxCorner, node.minCorner);
+    let axis = 0;
+    if (extent[1] > extent[axis]) axis = 1;
+    if (extent[2] > extent[axis]) axis = 2;
+    const splitPosition = node.minCorner[axis] + extent[axis] / 2;
+    let i = node.leftChildIndex;
+    let j = i + node.primitiveCount - 1;
+    while (i <= j) {
+      if (this.blasList[this.blasIndices[i]].center[axis] < splitPosition) {
+        i += 1;
+      } else {
+        const temp = this.blasIndices[i]; this.blasIndices[i] = this.blasIndices[j]; this.blasIndices[j] = temp;
+        j -= 1;
+      }
+    }
+    const leftCount = i - node.leftChildIndex;
+    if (leftCount == 0 || leftCount == node.primitiveCount) return;
+    const leftChildIndex = this.tlasNodesUsed; this.tlasNodesUsed += 1;
+    const rightChildIndex = this.tlasNodesUsed; this.tlasNodesUsed += 1;
+    this.nodes[leftChildIndex].leftChildIndex = node.leftChildIndex;
+    this.nodes[leftChildIndex].primitiveCount = leftCount;
+    this.nodes[rightChildIndex].leftChildIndex = i;
+    this.nodes[rightChildIndex].primitiveCount = node.primitiveCount - leftCount;
+    node.leftChildIndex = leftChildIndex;
+    node.primitiveCount = 0;
+    this.updateBounds(leftChildIndex);
+    this.updateBounds(rightChildIndex);
+    this.subdivide(leftChildIndex);
+    this.subdivide(rightChildIndex);
+  }
+  finalizeBVH() {                                                    // SR:256-272
+    for (const mesh of this.meshes) {
+      for (let i = 0; i < mesh.bvh.nodesUsed; ++i) {
+        const meshNode = mesh.bvh.nodes[i];
+        if (meshNode.primitiveCount == 0) meshNode.leftChildIndex += mesh.rootNodeIndex;
+        else meshNode.leftChildIndex += mesh.triangleLookupOffset;
+        this.nodes[mesh.rootNodeIndex + i] = meshNode;
+      }
+    }
+  }
 }
 module.exports = { SceneRaytracing, syntheticSpheres, SplitMix64, BASELINE_CONFIGS, CONSTANT_SKY_RGBA };

@@ -125,3 +125,87 @@ def test_node_renders_triangle_scene(tmp_path, oracle, heatmap):
         ref, _, rays = oracle.render_tri(scene.pack_params(B), b, sky.faces, W, H)
         assert res["rays"] == rays
     assert res["sha256"] == hashlib.sha256(ref.tobytes()).hexdigest()
+
+
+def _obj_spec():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import obj_floor, obj_uv_sphere
+    meshes = [
+        dict(obj=obj_uv_sphere(6, 8, 1.0), descriptor=dict(color=[0.9, 0.5, 0.3, 0.6], alignBottom=True, scale=1.0)),
+        dict(obj=obj_uv_sphere(5, 7, 1.0, quads=False), descriptor=dict(color=[0.3, 0.7, 0.9, 1.0], alignBottom=True, invertYZ=False, scale=0.7)),
+        dict(obj=obj_floor(1.0), descriptor=dict(color=[1.0, 1.0, 1.0, 0.8], scale=12)),
+    ]
+    models = [dict(meshIndex=0, position=[-2.0, 0, -6.0], eulers=[0, 30.0, 0], eulerSpeed=[0, 45.0, 0]),
+              dict(meshIndex=1, position=[2.5, 0, -7.5], eulers=[0, 200.0, 0], eulerSpeed=[0, -20.0, 0]),
+              dict(meshIndex=2, position=[0, 0, -5.0], eulers=[0, 0, 0], eulerSpeed=[0, 0, 0])]
+    return meshes, models
+
+
+def _python_scene(meshes, models, updates):
+    pm = [rt.Mesh().initializeFromText(m["obj"], m["descriptor"]) for m in meshes]
+    pmod = [rt.Model(m["meshIndex"], m["position"], m["eulers"], m["eulerSpeed"]) for m in models]
+    scene = rt.SceneRaytracing().createScene([])
+    scene.createTriangleScene(pm, pmod)
+    for dt in updates:
+        scene.update(dt)
+    return scene
+
+
+def test_js_scene_builders_match_python_mirror(tmp_path):
+    """OBJ reader -> SAH BVH -> Model matrices -> BLAS -> TLAS built twice, by node/*.js and by the
+    Python mirror: every packed f32 must agree bit for bit (two restatements of scene-raytracing.ts,
+    bvh.ts, blas.ts, model.ts, obj-reader.ts and of gl-matrix)."""
+    meshes, models = _obj_spec()
+    updates = [0.016, 0.25, 1.5]
+    spec = dict(width=64, height=48, bounces=2, meshes=meshes, models=models, updates=updates)
+    path = str(tmp_path / "spec.json")
+    json.dump(spec, open(path, "w"))
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "build-obj-scene.js"), path], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    js = json.loads(out.stdout.strip().splitlines()[-1])
+    scene = _python_scene(meshes, models, updates)
+    assert js["nTriangles"] == len(scene.triangles) and js["tlasNodesUsed"] == scene.tlasNodesUsed
+    assert js["tlasNodesMax"] == scene.tlasNodesMax and js["blasNodesUsed"] == scene.blasNodesUsed
+    assert js["blasIndices"] == list(scene.blasIndices) and js["triangleIndices"] == list(scene.triangleIndices)
+    pb = scene.pack_blas()
+    for i, b in enumerate(js["blas"]):
+        assert b == [int(v) for v in pb[i, :17].view(np.uint32)], i
+    nodes = np.zeros((len(scene.nodes), 8), np.float32)
+    t, bn = scene.pack_tlas_nodes(), scene.pack_blas_nodes()
+    # JS dumps every node slot as it stands; compare the used ones
+    for i in range(scene.tlasNodesUsed):
+        assert js["nodes"][i] == [int(v) for v in t[i].view(np.uint32)], i
+    for i in range(scene.blasNodesUsed):
+        assert js["nodes"][scene.tlasNodesMax + i] == [int(v) for v in bn[i].view(np.uint32)], i
+    t0 = scene.triangles[0]
+    want = np.concatenate([np.array(t0.corners[0]), np.array(t0.corners[1]), np.array(t0.corners[2]),
+                           np.array(t0.centroid, dtype=np.float64)]).astype(np.float32)
+    assert js["tri0"] == [int(v) for v in want.view(np.uint32)]
+
+
+@pytest.mark.gpu
+def test_node_builds_and_renders_obj_scene(tmp_path, oracle):
+    """The whole reference flow in Node: OBJ text -> scene build (JS) -> RendererRaytracing (JS) ->
+    N-API -> HIP; the frame is checked against the oracle fed with the Python mirror's buffers."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import tri_buffers
+    from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
+    meshes, models = _obj_spec()
+    rng = np.random.default_rng(3)
+    tex = rng.integers(0, 256, (8, 8, 4), dtype=np.uint8)
+    W, H, B = 200, 120, 3
+    spec = dict(width=W, height=H, bounces=B, meshes=meshes, models=models, updates=[0.5],
+                meshTexture=dict(width=8, height=8, data=tex.reshape(-1).tolist()))
+    path = str(tmp_path / "spec.json")
+    json.dump(spec, open(path, "w"))
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "build-obj-scene.js"), path, str(tmp_path / "o.rgba")],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    js = json.loads(out.stdout.strip().splitlines()[-1])
+    scene = _python_scene(meshes, models, [0.5])
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, rt.Material(tex)), sky.faces, W, H)
+    assert js["rays"] == rays and js["sha256"] == hashlib.sha256(ref.tobytes()).hexdigest()
