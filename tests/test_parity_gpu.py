@@ -264,3 +264,41 @@ def test_renderer_reuse_across_frames_and_camera_moves(oracle):
             assert r.render_time_ms is not None and r.stats()["frames"] == step + 1
     finally:
         r.close()
+
+
+def test_resize_and_repartition_between_frames(oracle):
+    """rt_resize / rt_set_partition are re-callable (the reference sizes its colour buffer once,
+    RR:102-109; a host may not): buffers and the path queue are regrown, frames stay exact."""
+    scene = rt.synthetic_scene(200, 31)
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    L = abi.load()
+    r = rt.RendererRaytracing(96, 64, scene, maxBounces=3).initialize(sky)
+    try:
+        for (w, h, rank, world) in [(96, 64, 0, 1), (320, 200, 0, 1), (64, 40, 1, 2), (64, 40, 0, 1), (400, 300, 2, 3)]:
+            abi.check(L.rt_set_partition(r._ctx, rank, world), r._ctx)
+            abi.check(L.rt_resize(r._ctx, w, h), r._ctx)
+            r.width, r.height, r.rank, r.world = w, h, rank, world
+            r.render()
+            img = r.read_pixels()
+            ref, _, _ = oracle.render(scene.pack_params(3), scene.pack_spheres(), sky.faces, w, h)
+            rows = [y for y in range(h) if (y // 8) % world == rank]
+            assert np.array_equal(img, ref[rows]), (w, h, rank, world)
+    finally:
+        r.close()
+
+
+def test_two_contexts_side_by_side(oracle):
+    a_scene, b_scene = rt.synthetic_scene(50, 1), rt.synthetic_scene(300, 2)
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    ra = rt.RendererRaytracing(128, 72, a_scene, maxBounces=2).initialize(sky)
+    rb = rt.RendererRaytracing(160, 96, b_scene, maxBounces=5).initialize(sky)
+    try:
+        ra.recalculateScene(); rb.recalculateScene()
+        ra.enqueue(); rb.enqueue(); ra.enqueue()
+        ra.wait(); rb.wait()
+        ia, ib = ra.read_pixels(), rb.read_pixels()
+        assert np.array_equal(ia, oracle.render(a_scene.pack_params(2), a_scene.pack_spheres(), sky.faces, 128, 72)[0])
+        assert np.array_equal(ib, oracle.render(b_scene.pack_params(5), b_scene.pack_spheres(), sky.faces, 160, 96)[0])
+        assert ra.stats()["frames"] == 2 and rb.stats()["frames"] == 1
+    finally:
+        ra.close(); rb.close()
