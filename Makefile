@@ -4,7 +4,7 @@ ARCH     ?= gfx950
 CSRC     := compute_raytracer_amd/csrc
 LIB      := compute_raytracer_amd/librt355.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-fast-math -Wall -Wno-unused-function $(EXTRA)
-OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_triangles.o $(CSRC)/rt_assemble.o
+OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_bvh.o $(CSRC)/rt_triangles.o $(CSRC)/rt_assemble.o
 
 all: lib oracle node
 
@@ -12,7 +12,10 @@ lib: $(LIB)
 
 # the ray-trace kernels: no FMA contraction, no SLP (packed-math) vectorisation -- see the
 # header of rt_kernels.hip
-$(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_types.h
+$(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_filter.h $(CSRC)/rt_device.h $(CSRC)/rt_types.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -fno-slp-vectorize -c $< -o $@
+
+$(CSRC)/rt_bvh.o: $(CSRC)/rt_bvh.hip $(CSRC)/rt_filter.h $(CSRC)/rt_device.h $(CSRC)/rt_types.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -fno-slp-vectorize -c $< -o $@
 
 $(CSRC)/rt_triangles.o: $(CSRC)/rt_triangles.hip $(CSRC)/rt_device.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h

@@ -11,6 +11,9 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
+
+uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4, std::vector<uint32_t>& link);   // rt_bvh.hip
 
 namespace {
 
@@ -54,6 +57,15 @@ struct rt_ctx {
     float4* d_scene = nullptr;           // 8 float4 arrays of n16: geo lgt cam col geo_f lgt_f cam_f + {geo_w,lgt_w,cam_w,-}
     uint32_t n16 = 0;                    // n rounded up to a multiple of 16
     float scene_bound = 0.0f;            // max over spheres of |center| + radius (host side)
+    // bounding-sphere hierarchy (rt_bvh.hip): host copy of the records it is built from, the
+    // build result and its device copy
+    std::vector<float> h_records;
+    std::vector<float> h_bvh_rec;
+    std::vector<uint32_t> h_bvh_link;
+    float4* d_bvh_rec = nullptr;
+    uint32_t* d_bvh_link = nullptr;
+    uint32_t bvh_cap = 0, bvh_nodes = 0;
+    bool bvh_valid = false;              // built for the current spheres
     uint8_t* d_face[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
     uint8_t* d_out = nullptr;
@@ -131,6 +143,8 @@ int rt_destroy(rt_ctx* c) {
     for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
     (void)hipFree(c->d_out);
     (void)hipFree(c->d_queue);
+    (void)hipFree(c->d_bvh_rec);
+    (void)hipFree(c->d_bvh_link);
     for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_nodes, &c->d_blas, &c->d_tri_lookup, &c->d_blas_lookup, &c->d_tex})
         (void)hipFree(b->p);
     (void)hipFree(c->d_rays);
@@ -235,6 +249,8 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
     c->n = n;
     c->scene_kind = 0;
     c->n16 = (n + 15u) & ~15u;
+    c->h_records.assign(records, records + 8u * (size_t)n);   // the hierarchy is built lazily from this copy
+    c->bvh_valid = false;
     {   // scene extent, for the sign-aware filter (rt_kernels.hip: filter_one)
         double bound = 0.0;
         for (uint32_t i = 0; i < n; ++i) {
@@ -415,15 +431,42 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         const float* w = reinterpret_cast<const float*>(b + 7u * m);
         fa.geo_w = w; fa.lgt_w = w + m; fa.cam_w = w + 2u * m;
     }
-    {   // sign-aware filter only while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays
-        // below half of the 0.001 a valid hit needs (rt_kernels.hip: filter_one)
+    // reach: bound on |ray origin| and on |center| + radius.  The sign-aware filter is valid only
+    // while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays below half of the 0.001 a
+    // valid hit needs (rt_filter.h: filter_one); beyond 2^20 (or NaN) the 2^40-scaled filter
+    // arithmetic could overflow, and the frame is rendered by the literal kernel instead.
+    double reach = c->scene_bound;
+    {
         const float* p = c->params;
         const double cam = std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
         const double lgt = std::sqrt((double)p[16] * p[16] + (double)p[17] * p[17] + (double)p[18] * p[18]);
-        double reach = c->scene_bound;
         if (!(cam <= reach)) reach = cam;
         if (!(lgt <= reach)) reach = lgt;
         fa.signed_filter = (reach == reach && 2.0 * reach * 7.3e-7 < 5.0e-4) ? 1u : 0u;
+    }
+    const bool filter_ok = reach < 1048576.0;
+    // variant 4: bounding-sphere hierarchy, (re)built when the spheres changed
+    const bool use_bvh = !tri && c->mode == RT_MODE_FAST && c->variant == 4 && filter_ok && c->n > 0;
+    fa.bvh_rec = nullptr; fa.bvh_link = nullptr; fa.bvh_nodes = 0;
+    if (use_bvh) {
+        if (!c->bvh_valid) {
+            const uint32_t nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link);
+            if (nodes + 1u > c->bvh_cap) {
+                RT_HIP(hipStreamSynchronize(s));
+                (void)hipFree(c->d_bvh_rec); (void)hipFree(c->d_bvh_link);
+                c->d_bvh_rec = nullptr; c->d_bvh_link = nullptr; c->bvh_cap = 0;
+                RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_rec), ((size_t)nodes + 1u) * sizeof(float4)));
+                RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_link), ((size_t)nodes + 1u) * sizeof(uint32_t)));
+                c->bvh_cap = nodes + 1u;
+            }
+            RT_HIP(hipMemcpyAsync(c->d_bvh_rec, c->h_bvh_rec.data(), ((size_t)nodes + 1u) * sizeof(float4), hipMemcpyHostToDevice, s));
+            RT_HIP(hipMemcpyAsync(c->d_bvh_link, c->h_bvh_link.data(), ((size_t)nodes + 1u) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            RT_HIP(hipStreamSynchronize(s));   // pageable sources: the vectors may be rebuilt next frame
+            RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, nodes, fa.geo_f, s));
+            c->bvh_nodes = nodes;
+            c->bvh_valid = true;
+        }
+        fa.bvh_rec = c->d_bvh_rec; fa.bvh_link = c->d_bvh_link; fa.bvh_nodes = c->bvh_nodes;
     }
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
     fa.out = dst;
@@ -432,7 +475,7 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     fa.qctrl = reinterpret_cast<uint32_t*>(c->d_rays) + 2;
     fa.queue_cap = (uint32_t)c->queue_cap;
     RtLaunchCfg cfg;
-    cfg.mode = c->mode;
+    cfg.mode = filter_ok ? c->mode : (int)RT_MODE_STRICT;
     cfg.variant = c->variant;
 
     RT_HIP(hipEventRecord(c->ev_k0[slot], s));
@@ -452,7 +495,8 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
     } else {
-        RT_HIP(rt_launch_trace(fa, cfg, s));
+        if (use_bvh) RT_HIP(rt_launch_bvh(fa, s));
+        else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
     RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -1,0 +1,421 @@
+// rt_bvh.hip -- sphere scenes through a bounding-sphere hierarchy (variant 4, "hierarchy").
+//
+// The reference traces sphere scenes by testing every sphere (HK:307-331 inside the loop of
+// RK:168-244's predecessor); the brute-force kernels of rt_kernels.hip do the same and are bound
+// by the FMA pipe.  This file reaches the same pixels -- bit for bit -- with far fewer tests:
+//
+//   * the host builds, once per rt_write_spheres, a 4-ary hierarchy of bounding SPHERES over the
+//     scene's spheres and stores it in depth-first order with skip links ("threaded" tree): a
+//     ray walks the array front to back, `i = pass ? i + 1 : skip[i]`, no stack;
+//   * an inner node is tested with the same conservative discriminant filter as a sphere
+//     (rt_filter.h: 8 v_fma_f32 + v_min_f32 + v_cmp), on a record of the same layout
+//     {C * 2^40, (|C|^2 (1-eps) - R^2 (1+kappa)) * 2^80}; its radius R covers every member sphere
+//     with the slack derived below, so a node can only be skipped when no member can be hit;
+//   * a leaf is one sphere: its record IS the filter record of rt_kernels.hip (geo_f), a lane
+//     whose ray passes it appends the sphere index to its candidate list in LDS;
+//   * after the walk every lane evaluates its candidates with the reference's literal
+//     arithmetic (exact_full) and keeps the lexicographic minimum of (t, index) -- exactly what
+//     the reference's in-order loop with `t < nearest` keeps;
+//   * nodes and links are staged in LDS (20 B per node, ~1.35 nodes per sphere); lanes read them
+//     with divergent addresses, so the kernel is bound by LDS bandwidth, not by the FMA pipe.
+//
+// One persistent kernel renders the frame: every lane carries one path through a small state
+// machine (reflection ray -> shadow ray -> next bounce ...) and takes the next pixel from an
+// atomic cursor when its path ends, so all 64 lanes of a wave walk the hierarchy together
+// whatever their bounce depth; there is no path queue and no second kernel.
+//
+// Why a node test cannot lose a hit.  Notation: unit direction h, leaf sphere (c, r) with
+// L = |o - c|, node (C, R), D = |C - c| <= Rg - r where Rg = max over members (|C - c_i| + r_i);
+// rho_x = distance of the ray's LINE from x, T = h.(C - o); u = 2^-24, kappa = 2^-16.
+//   1. A literal hit (HK:316-318) needs disc > 0 and t > 0.001.  The rounding of the literal
+//      discriminant is below 24u (L^2 + r^2) =: d, so rho_c^2 <= r^2 + d, and t > 0.001 puts c in
+//      front of the origin (the host allows the sign-aware form only for reach < 342, where the
+//      rounding of h.oc cannot flip that).
+//   2. The node test evaluates, in the filter's fused form (rt_filter.h), a value that exceeds
+//      (1+kappa)^2 T^2 - |o-C|^2 + R^2 by more than its own rounding (the eps terms), so it passes
+//      whenever rho_C^2 < R^2 + 2 kappa T^2.  The stored radius is R = Rg (1 + sigma), sigma = 0.16:
+//      near origins, L < 128 Rg:  sqrt(d) < 0.154 Rg, so rho_C <= sqrt(r^2 + d) + D < Rg (1 + sigma) = R;
+//      far origins,  L >= 128 Rg: rho_C^2 - Rg^2 <= d + 2 D sqrt(d) <= (1.43e-6 + 1.87e-5) L^2, while
+//                                 T >= 0.99 L gives 2 kappa T^2 >= 2.99e-5 L^2.
+//   3. Sign-aware form min(b,0)^2 - (|o-C|^2 - R^2) > 0: a computed b < 0 is the unsigned test.  A
+//      computed b >= 0 means T <= 7.3e-7 |o-C| while c is ahead; with P the point of closest
+//      approach to c, |o-C|^2 = |P-C|^2 - t_c^2 + 2 t_c T <= (D + sqrt(r^2+d))^2 (1 + 2e-6) < R^2:
+//      the origin is inside the node and the test passes on its second term.
+// The argument is checked the only way that counts: frames are compared bit for bit with the
+// oracle (tests/test_bvh_gpu.py: golden frames, random scenes over five orders of magnitude).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "rt_filter.h"
+
+// ---- host: hierarchy build ---------------------------------------------------------------------------
+namespace {
+
+struct Builder {
+    const float* rec;              // [n][8] {cx,cy,cz,_, r,g,b, radius}
+    std::vector<float>& out_rec;   // 4 floats per node
+    std::vector<uint32_t>& out_link;
+    std::vector<uint32_t> ids;
+
+    double cx(uint32_t i, int a) const { return (double)rec[8u * (size_t)i + (size_t)a]; }
+    double rad(uint32_t i) const { return std::fabs((double)rec[8u * (size_t)i + 7u]); }
+
+    void leaf(uint32_t sphere) {
+        out_rec.insert(out_rec.end(), {0.0f, 0.0f, 0.0f, 0.0f});   // filled on the device from geo_f
+        out_link.push_back(0x80000000u | sphere);
+    }
+
+    // longest axis of the centres' box, median split (ties by sphere index: deterministic)
+    uint32_t split2(uint32_t lo, uint32_t hi) {
+        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t k = lo; k < hi; ++k)
+            for (int a = 0; a < 3; ++a) {
+                const double v = cx(ids[k], a);
+                mn[a] = std::min(mn[a], v); mx[a] = std::max(mx[a], v);
+            }
+        int ax = 0;
+        if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+        if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [&](uint32_t a, uint32_t b) {
+            const double va = cx(a, ax), vb = cx(b, ax);
+            return va < vb || (va == vb && a < b);
+        });
+        return mid;
+    }
+
+    void bound(uint32_t lo, uint32_t hi, float out[4]) {
+        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t k = lo; k < hi; ++k)
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], cx(ids[k], a) - rad(ids[k]));
+                mx[a] = std::max(mx[a], cx(ids[k], a) + rad(ids[k]));
+            }
+        const float C[3] = {(float)(0.5 * (mn[0] + mx[0])), (float)(0.5 * (mn[1] + mx[1])), (float)(0.5 * (mn[2] + mx[2]))};
+        double R = 0.0;
+        for (uint32_t k = lo; k < hi; ++k) {
+            const uint32_t i = ids[k];
+            const double dx = cx(i, 0) - C[0], dy = cx(i, 1) - C[1], dz = cx(i, 2) - C[2];
+            const double r = rad(i);
+            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + r);
+        }
+        R *= 1.16;            // sigma, see the header
+        const double c2 = (double)C[0] * C[0] + (double)C[1] * C[1] + (double)C[2] * C[2];
+        const double k = c2 * (1.0 - (double)RT_FILTER_EPS) - R * R * (1.0 + (double)RT_FILTER_KAPPA);
+        out[0] = C[0] * RT_FILTER_SCALE; out[1] = C[1] * RT_FILTER_SCALE; out[2] = C[2] * RT_FILTER_SCALE;
+        out[3] = (float)(k * (double)RT_FILTER_SCALE2);
+    }
+
+    void emit(uint32_t lo, uint32_t hi) {
+        if (hi - lo == 1u) { leaf(ids[lo]); return; }
+        const size_t me = out_link.size();
+        out_rec.insert(out_rec.end(), {0.0f, 0.0f, 0.0f, 0.0f});
+        out_link.push_back(0u);
+        children(lo, hi);
+        float b[4];
+        bound(lo, hi, b);
+        std::copy(b, b + 4, out_rec.begin() + 4 * me);
+        out_link[me] = (uint32_t)out_link.size();       // skip link: first node after this subtree
+    }
+
+    // up to four children: two median splits
+    void children(uint32_t lo, uint32_t hi) {
+        if (hi - lo <= 4u) {
+            for (uint32_t k = lo; k < hi; ++k) leaf(ids[k]);
+            return;
+        }
+        const uint32_t mid = split2(lo, hi);
+        const uint32_t q1 = split2(lo, mid), q3 = split2(mid, hi);
+        emit(lo, q1); emit(q1, mid); emit(mid, q3); emit(q3, hi);
+    }
+};
+
+}  // namespace
+
+// Builds the threaded hierarchy.  Top level: spheres much larger than the scene (a ground
+// sphere) as leaves of their own -- inside a node they would inflate it to cover everything --,
+// then up to four subtrees over the rest.  Returns the node count n; the arrays hold n + 1
+// entries, the last one being the sentinel the traversal loop parks finished lanes on.
+uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4, std::vector<uint32_t>& link) {
+    rec4.clear(); link.clear();
+    if (n == 0) return 0;
+    rec4.reserve((size_t)n * 6u); link.reserve((size_t)n * 3u / 2u + 8u);
+    Builder b{records, rec4, link, {}};
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.cx(i, a)); mx[a] = std::max(mx[a], b.cx(i, a)); }
+    // median radius: a sphere is "large" when it exceeds 8 medians AND an eighth of the centres' extent
+    std::vector<double> radii(n);
+    for (uint32_t i = 0; i < n; ++i) radii[i] = b.rad(i);
+    std::nth_element(radii.begin(), radii.begin() + n / 2u, radii.end());
+    const double med = radii[n / 2u];
+    const double ext = std::sqrt((mx[0] - mn[0]) * (mx[0] - mn[0]) + (mx[1] - mn[1]) * (mx[1] - mn[1]) + (mx[2] - mn[2]) * (mx[2] - mn[2]));
+    uint32_t big = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool large = n > 8u && b.rad(i) > 8.0 * med && b.rad(i) > 0.125 * ext;
+        if (large && big < 64u) { b.leaf(i); ++big; } else b.ids.push_back(i);
+    }
+    if (!b.ids.empty()) b.children(0u, (uint32_t)b.ids.size());
+    const uint32_t nodes = (uint32_t)link.size();
+    rec4.insert(rec4.end(), {0.0f, 0.0f, 0.0f, INFINITY});   // sentinel [nodes]: never passes, links to itself
+    link.push_back(nodes);
+    return nodes;
+}
+
+namespace rtk {
+
+// ---- device: leaf records = the filter records prep_spheres wrote ------------------------------------
+__global__ void bvh_fill_leaves(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t l = link[i];
+    if (l & 0x80000000u) rec[i] = geo_f[l & 0x7FFFFFFFu];
+}
+
+#ifdef RT_BVH_COUNT
+#define g_steps steps_acc
+#endif
+__device__ __forceinline__ float min0(float b) {      // min(b, 0) without the IEEE canonicalisation
+    float d; asm("v_min_f32 %0, 0, %1" : "=v"(d) : "v"(b)); return d;
+}
+
+// literal test of one candidate, lexicographic (t, index) minimum (== in-order `t < nearest`)
+__device__ __forceinline__ void exact_any_order(v3 center, float r2, int s, v3 o, v3 d, float fa, float ta,
+                                                float& nearest, int& idx) {
+    const v3 oc = sub(o, center);
+    const float b = 2.0f * dot(d, oc);              // HK:309
+    const float c = dot(oc, oc) - r2;               // HK:310
+    const float disc = b * b - fa * c;              // HK:311
+    if (disc > 0.0f && b < 0.0f) {                  // HK:316; b >= 0 gives t <= 0 (see exact_full)
+        const float t = (-b - sqrtf(disc)) / ta;    // HK:317
+        if (t > 0.001f && (t < nearest || (t == nearest && idx >= 0 && s < idx))) {   // HK:318
+            nearest = t;
+            idx = s;
+        }
+    }
+}
+
+// Nearest hit of the ray (o, d) of every ACTIVE lane.  R/L: node records and links (LDS or
+// global), n: node count, geo: exact {c, r*r}.  slot: this lane's candidate column ([k*64]).
+template <bool SGN, int CAP>
+__device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
+                                          const float4* __restrict__ geo, uint32_t* slot, bool active, v3 o, v3 d,
+                                          float& nearest, int& idx
+#ifdef RT_BVH_COUNT
+                                          , uint32_t& steps_acc
+#endif
+                                          ) {
+    const float a = dot(d, d);           // HK:308
+    const float fa = 4.0f * a;           // the (4*a) of HK:311
+    const float ta = 2.0f * a;           // HK:317
+    const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_FILTER_KAPPA);
+    const v3 h = V(d.x * inv, d.y * inv, d.z * inv);
+    const v3 os = V(o.x * RT_FILTER_SCALE, o.y * RT_FILTER_SCALE, o.z * RT_FILTER_SCALE);   // exact
+    const v3 m = V(-2.0f * os.x, -2.0f * os.y, -2.0f * os.z);
+    const float p = dot(h, os);
+    const float q = dot(os, os) * (1.0f - RT_FILTER_EPS);
+    nearest = 9999.0f;                   // RK:172
+    idx = -1;
+    uint32_t* wp = slot;                 // next free entry of this lane's candidate column
+
+    auto drain = [&]() {
+        for (uint32_t* rp = slot; __ballot(rp < wp) != 0ull; rp += 64) {
+            if (rp < wp) {
+                const int si = (int)(*rp & 0x7FFFFFFFu);
+                const float4 g = geo[si];
+                exact_any_order(V(g.x, g.y, g.z), g.w, si, o, d, fa, ta, nearest, idx);
+            }
+        }
+        wp = slot;
+    };
+
+    // node n is a sentinel that never passes and links to itself: a lane that is done (or has
+    // no ray) idles on it without an exec-mask test per step; the wave leaves the loop when
+    // every lane sits there.  Two steps per trip halve the loop overhead.
+    auto step = [&](uint32_t i) -> uint32_t {
+        const float4 g = R[i];
+        const uint32_t lk = L[i];
+        const float b = fnma_vvv(h.z, g.z, fnma_vvv(h.y, g.y, fnma_vvv(h.x, g.x, p)));
+        const float cp = fma_vvv(m.z, g.z, fma_vvv(m.y, g.y, fma_vvv(m.x, g.x, g.w)));
+        const float bm = SGN ? min0(b) : b;
+        const bool pass = __builtin_fmaf(bm, bm, -q) > cp;
+        const bool leaf = (int)lk < 0;
+        if (leaf && pass) {
+            *wp = lk;
+            wp += 64;
+        }
+        return (leaf || pass) ? i + 1u : lk;
+    };
+    uint32_t i = active ? 0u : n;
+    while (__ballot(i != n) != 0ull) {
+#ifdef RT_BVH_COUNT   // development statistics: 1 = wave iterations, 2 = lane tests (reported as "rays")
+        if (RT_BVH_COUNT == 1) g_steps += (threadIdx.x & 63u) == 0u ? 2u : 0u;
+        if (RT_BVH_COUNT == 2) g_steps += i != n ? 1u : 0u;
+#endif
+        i = step(i);
+#ifdef RT_BVH_COUNT
+        if (RT_BVH_COUNT == 2) g_steps += i != n ? 1u : 0u;
+#endif
+        i = step(i);
+        if (__ballot(wp >= slot + (CAP - 1) * 64) != 0ull) drain();
+    }
+    drain();
+}
+
+// ---- kernel ---------------------------------------------------------------------------------------------
+// NLDS: node records and links staged in LDS (else read from global memory / L2: any scene size).
+template <int WAVES, bool SGN, bool NLDS, int CAP>
+__global__ __launch_bounds__(64 * WAVES) void bvh_pixels(const RtFrameArgs A) {
+    extern __shared__ float4 lds[];
+    const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
+    const uint32_t n4 = (n + 4u) & ~3u;
+    float4* sR = lds;
+    uint32_t* sL = reinterpret_cast<uint32_t*>(lds + (NLDS ? n4 : 0u));
+    uint32_t* lists = sL + (NLDS ? n4 : 0u);
+    if (NLDS) {
+        for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) { sR[i] = A.bvh_rec[i]; sL[i] = A.bvh_link[i]; }
+        __syncthreads();
+    }
+    const float4* R = NLDS ? sR : A.bvh_rec;
+    const uint32_t* L = NLDS ? sL : A.bvh_link;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* slot = lists + wave * (uint32_t)(CAP * 64) + lane;
+
+    const Scene sc = unpack_scene(A);
+    const uint32_t tiles_x = (A.W + 7u) / 8u;
+    const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
+    uint32_t cur = 0, end = 0;                                   // wave-uniform chunk cursor
+    bool exhausted = false;
+
+    // per-lane path state (RK:101-144 unrolled into a state machine)
+    bool active = false, shadow = false;
+    uint32_t opix = 0, px = 0, py = 0, bounce = 0, nrays = 0;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(1, 1, 1);
+    v3 normal = V(0, 0, 1), sdir = V(0, 0, 1), albedo = V(0, 0, 0);
+    float dist = 0.0f, affect = 1.0f, sum = 0.0f, distance = 1.0f;
+
+    for (;;) {
+        // ---- idle lanes take the next pixels ----
+        uint64_t idle = __ballot(!active);
+        while (idle && !exhausted) {
+            if (cur == end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&A.qctrl[2], 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= total) { exhausted = true; break; }
+                cur = base;
+                end = min(base + 64u, total);
+            }
+            const uint32_t take = min((uint32_t)__popcll(idle), end - cur);
+            const uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && r < take) {
+                const uint32_t id = cur + r, tile = id >> 6, l = id & 63u;
+                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                const uint32_t x = tx * 8u + (l & 7u), row = l >> 3;
+                const uint32_t y = (A.tile_first + ty * A.tile_step) * 8u + row;
+                if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
+                    px = x; py = y;
+                    opix = (ty * 8u + row) * A.W + x;
+                    ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
+                    color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
+                    affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
+                    shadow = false;
+                    active = true;
+                }
+            }
+            cur += take;
+            idle = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+
+        bool finished = active && sc.bounces == 0u;              // RK:113: the loop body never runs
+        const bool tracing = active && !finished;
+        float t; int idx;
+#ifdef RT_BVH_COUNT
+        trace_bvh<SGN, CAP>(R, L, n, A.geo, slot, tracing, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
+        if (tracing) {
+#else
+        trace_bvh<SGN, CAP>(R, L, n, A.geo, slot, tracing, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
+        if (tracing) {
+            ++nrays;
+#endif
+            const float next = affect + sum;                             // RK:120
+            if (!shadow) {
+                if (bounce == 0u) dist = idx >= 0 ? t : 0.0f;            // RK:116-118
+                if (idx < 0) {                                           // RK:122-126
+                    const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
+                    color = divs(add(scale(sum, color), scale(affect, sky)), next);
+                    finished = true;
+                } else {
+                    const float4 g = A.geo[idx];
+                    const float4 cl4 = A.col[idx];
+                    albedo = V(cl4.x, cl4.y, cl4.z);
+                    const v3 pos = add(ro, scale(t, rd));                    // RK:129
+                    normal = normalize(sub(pos, V(g.x, g.y, g.z)));          // HK:320
+                    ro = pos;
+                    rd = normalize(reflect(rd, normal));                     // RK:130
+                    sdir = normalize(sub(ro, sc.lightPos));                  // RK:147
+                    distance = length(sdir);                                 // RK:148
+                    shadow = true;                                           // RK:153 next
+                }
+            } else {
+                const float intensity = light_term(sc, ro, normal, sdir, distance, idx >= 0, t);
+                const v3 blended = scale(intensity, albedo);                 // RK:133-135
+                color = divs(add(scale(sum, color), scale(affect, blended)), next);   // RK:136
+                affect = affect / 2.0f;                                      // RK:139
+                sum = next;                                                  // RK:140
+                ++bounce;
+                shadow = false;
+                finished = bounce >= sc.bounces;                             // RK:113
+            }
+        }
+        if (finished) {
+            const v3 dir0 = primary_dir(A, sc, px, py);
+            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, dir0, color, dist);   // RK:91-98
+            active = false;
+        }
+    }
+    count_rays(A.rays, nrays);
+}
+
+template <int WAVES, bool SGN, bool NLDS, int CAP>
+hipError_t launch_bvh_as(const RtFrameArgs& a, size_t lds, hipStream_t s) {
+    auto k = bvh_pixels<WAVES, SGN, NLDS, CAP>;
+    if (lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const size_t cap = 160u * 1024u;
+    const uint32_t per_cu = (uint32_t)std::min((size_t)(32 / WAVES), cap / std::max(lds, (size_t)1));
+    const uint32_t pixels = a.n_local_tiles * ((a.W + 7u) / 8u) * 64u;
+    uint32_t blocks = 256u * (per_cu ? per_cu : 1u);
+    const uint32_t need = (pixels + 64u * WAVES - 1u) / (64u * WAVES);
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
+    return hipGetLastError();
+}
+
+template <bool SGN>
+hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
+    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    constexpr int CAP = 8;
+    const size_t n4 = ((size_t)a.bvh_nodes + 4u) & ~(size_t)3u;
+    const size_t nodes = n4 * 20u;
+    const size_t cap = 160u * 1024u;
+    if (nodes + 8u * CAP * 256u <= cap / 2u) return launch_bvh_as<8, SGN, true, CAP>(a, nodes + 8u * CAP * 256u, s);
+    if (nodes + 16u * CAP * 256u <= cap)     return launch_bvh_as<16, SGN, true, CAP>(a, nodes + 16u * CAP * 256u, s);
+    return launch_bvh_as<8, SGN, false, CAP>(a, 8u * CAP * 256u, s);
+}
+
+}  // namespace rtk
+
+hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s) {
+    return a.signed_filter ? rtk::launch_bvh<true>(a, s) : rtk::launch_bvh<false>(a, s);
+}
+
+hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    hipLaunchKernelGGL(rtk::bvh_fill_leaves, dim3((n_nodes + 255u) / 256u), dim3(256), 0, s, rec, link, n_nodes, geo_f);
+    return hipGetLastError();
+}

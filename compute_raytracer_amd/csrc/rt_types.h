@@ -47,6 +47,10 @@ struct RtFrameArgs {
     uint32_t* qctrl;           // [0] entries appended by the first-bounce kernel, [1] pop cursor,
                                // [2] tile-pair cursor of the first-bounce kernel
     uint32_t queue_cap;
+    // bounding-sphere hierarchy of the sphere scene (rt_bvh.hip), depth-first with skip links
+    const float4* bvh_rec;     // [bvh_nodes] node records, same layout as geo_f (leaves ARE geo_f records)
+    const uint32_t* bvh_link;  // [bvh_nodes] inner node: index after its subtree; leaf: 0x80000000 | sphere
+    uint32_t bvh_nodes;        // 0: no hierarchy built
 };
 
 struct RtPrepArgs {
@@ -65,5 +69,7 @@ struct RtLaunchCfg {
 
 hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
+hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s);
+hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t W, uint32_t H,
                               uint32_t world, uint32_t padded_tiles, hipStream_t s);

@@ -1,0 +1,103 @@
+"""Variant 4 (rt_bvh.hip): sphere scenes through the bounding-sphere hierarchy.  The hierarchy
+only decides which spheres are evaluated; every pixel must still be the oracle's, bit for bit:
+golden frames of the BASELINE configs, random scenes over many orders of magnitude of size and
+offset (the node radii carry a slack derived from the scene's reach), degenerate scenes (one
+sphere, coincident spheres, camera inside a sphere), the global-memory fallback for scenes whose
+nodes exceed the LDS, the multi-rank tile partition, and a moving camera that leaves the reach
+the hierarchy was built for."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import compute_raytracer_amd as rt
+from compute_raytracer_amd.scene_raytracing import synthetic_spheres
+from helpers import config_inputs, diff_stats, gpu_render, oracle_render
+from test_filter_fuzz_gpu import fuzz_scene
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BVH = 4
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3"])
+def test_golden_frames(name):
+    meta = json.load(open(os.path.join(GOLDEN, "frames.json")))[name]
+    cfg, scene = config_inputs(name)
+    img, st = gpu_render(scene, cfg["width"], cfg["height"], cfg["bounces"], strict=False, variant=BVH)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == meta["sha256"]
+    assert st["rays"] == meta["rays"]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_hierarchy_never_loses_a_hit(oracle, seed):
+    scene, info = fuzz_scene(1000 + seed)
+    W, H, B = 96, 64, 5
+    ref, _, rays = oracle_render(oracle, scene, W, H, B)
+    img, st = gpu_render(scene, W, H, B, strict=False, variant=BVH)
+    assert np.array_equal(img, ref), (info, diff_stats(img, ref))
+    assert st["rays"] == rays, info
+
+
+def test_degenerate_scenes(oracle):
+    cases = {
+        "one": [rt.Sphere([0, 1, -6], 1.0, [0.9, 0.2, 0.2])],
+        "two_coincident": [rt.Sphere([0, 1, -6], 1.0, [0.9, 0.2, 0.2]), rt.Sphere([0, 1, -6], 1.0, [0.2, 0.9, 0.2])],
+        "nine_on_a_line": [rt.Sphere([i - 4.0, 1, -8], 0.45, [0.5, 0.5, 0.9]) for i in range(9)],
+        "nested": [rt.Sphere([0, 1, -6], r, [0.3 + 0.1 * k, 0.5, 0.7]) for k, r in enumerate([0.2, 0.5, 1.0, 2.0, 4.0, 8.0])],
+    }
+    for name, spheres in cases.items():
+        scene = rt.SceneRaytracing().createScene(spheres)
+        ref, _, rays = oracle_render(oracle, scene, 80, 56, 4)
+        img, st = gpu_render(scene, 80, 56, 4, strict=False, variant=BVH)
+        assert np.array_equal(img, ref), (name, diff_stats(img, ref))
+        assert st["rays"] == rays, name
+
+
+def test_zero_bounces_and_no_spheres(oracle):
+    scene = rt.SceneRaytracing().createScene(synthetic_spheres(40, 11))
+    ref, _, rays = oracle_render(oracle, scene, 64, 40, 0)
+    img, st = gpu_render(scene, 64, 40, 0, strict=False, variant=BVH)
+    assert np.array_equal(img, ref) and st["rays"] == rays == 0
+
+
+def test_large_scene_nodes_in_global_memory(oracle):
+    # 9000 spheres: ~12000 nodes = 240 KB, more than a CU's LDS -> the global-memory instantiation
+    scene = rt.SceneRaytracing().createScene(synthetic_spheres(9000, 77))
+    ref, _, rays = oracle_render(oracle, scene, 160, 96, 3)
+    img, st = gpu_render(scene, 160, 96, 3, strict=False, variant=BVH)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays
+
+
+def test_partitioned_ranks_reassemble(oracle):
+    scene = rt.SceneRaytracing().createScene(synthetic_spheres(300, 5))
+    W, H, B, world = 200, 123, 4, 3
+    ref, _, rays = oracle_render(oracle, scene, W, H, B)
+    total = 0
+    frame = np.zeros((H, W, 4), np.uint8)
+    for rank in range(world):
+        img, st = gpu_render(scene, W, H, B, strict=False, variant=BVH, rank=rank, world=world)
+        rows = [y for t in range(rank, (H + 7) // 8, world) for y in range(t * 8, min(t * 8 + 8, H))]
+        frame[rows] = img.reshape(-1, W, 4)[: len(rows)]
+        total += st["rays"]
+    assert np.array_equal(frame, ref) and total == rays
+
+
+def test_camera_leaves_the_reach_the_hierarchy_was_built_for(oracle):
+    scene = rt.SceneRaytracing().createScene(synthetic_spheres(200, 9))
+    r = rt.RendererRaytracing(96, 64, scene, maxBounces=4)
+    r.initialize(None)
+    r.set_mode(False)
+    r.set_variant(BVH)
+    for step in range(4):           # camera backs away by x10 per frame: 3.3 -> 3300 units
+        scene.camera.position = [0.06, 2.7 * (1 + step), 3.3 * 10.0 ** step]
+        scene.camera.update()
+        r.render()
+        img = r.read_pixels()
+        ref, _, rays = oracle_render(oracle, scene, 96, 64, 4)
+        assert np.array_equal(img, ref), (step, diff_stats(img, ref))
+        assert r.stats()["rays"] == rays
+    r.close()

@@ -1,0 +1,171 @@
+"""Design study (CPU, float64): tests per ray of the threaded bounding-sphere hierarchy of
+rt_bvh.hip for different build strategies, on rays of a BASELINE scene (primary, reflection and
+shadow rays of a sample of 8x8 tiles).  Reports mean tests per ray and the per-wave maximum
+(what a wave of 64 lanes actually pays).  Not product code.
+usage: python tools/bvh_sim.py [C3] [ntiles]"""
+import sys, os, math
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from compute_raytracer_amd.scene_raytracing import synthetic_spheres, BASELINE_CONFIGS, SceneRaytracing
+
+cfgname = sys.argv[1] if len(sys.argv) > 1 else "C3"
+ntiles = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+cfg = BASELINE_CONFIGS[cfgname]
+sph = synthetic_spheres(cfg["spheres"], cfg["seed"])
+C = np.array([s.center for s in sph], dtype=np.float64)
+R = np.array([s.radius for s in sph], dtype=np.float64)
+N = len(R)
+SIGMA = 1.16
+
+
+def bound_box(ids):
+    lo = (C[ids] - R[ids, None]).min(0); hi = (C[ids] + R[ids, None]).max(0)
+    bc = 0.5 * (lo + hi)
+    return bc, (np.linalg.norm(C[ids] - bc, axis=1) + R[ids]).max()
+
+
+def bound_ritter(ids):
+    bc, br = bound_box(ids)
+    # shrink-wrap iterations: move the centre towards the farthest member
+    for _ in range(32):
+        d = np.linalg.norm(C[ids] - bc, axis=1) + R[ids]
+        k = int(np.argmax(d))
+        step = (C[ids[k]] - bc)
+        nrm = np.linalg.norm(step)
+        if nrm < 1e-12: break
+        cand = bc + step / nrm * 0.05 * d[k]
+        r2 = (np.linalg.norm(C[ids] - cand, axis=1) + R[ids]).max()
+        if r2 < br: bc, br = cand, r2
+        else: break
+    return bc, br
+
+
+def split_median(ids, bound):
+    lo = C[ids].min(0); hi = C[ids].max(0)
+    ax = int(np.argmax(hi - lo))
+    o = ids[np.argsort(C[ids, ax], kind="stable")]
+    h = len(o) // 2
+    return o[:h], o[h:]
+
+
+def split_sah(ids, bound):
+    best = None
+    for ax in range(3):
+        o = ids[np.argsort(C[ids, ax], kind="stable")]
+        n = len(o)
+        for h in range(1, n):
+            if n > 16 and h % max(1, n // 16): continue
+            _, ra = bound(o[:h]); _, rb = bound(o[h:])
+            cost = ra * ra * h + rb * rb * (n - h)
+            if best is None or cost < best[0]: best = (cost, o[:h], o[h:])
+    return best[1], best[2]
+
+
+def build(split, bound, leafmax=4, arity=4):
+    rec = []; link = []
+    def leaf(i):
+        rec.append((C[i], R[i])); link.append(("l", i))
+    def emit(ids):
+        if len(ids) == 1: leaf(ids[0]); return
+        me = len(rec); rec.append(None); link.append(None)
+        children(ids)
+        bc, br = bound(ids)
+        rec[me] = (bc, br * SIGMA); link[me] = ("n", len(rec))
+    def children(ids):
+        if len(ids) <= leafmax:
+            for i in ids: leaf(i)
+            return
+        parts = [ids]
+        while len(parts) < arity:
+            parts.sort(key=len, reverse=True)
+            big = parts.pop(0)
+            if len(big) < 2: parts.append(big); break
+            a, b = split(big, bound)
+            parts += [a, b]
+        for p in parts: emit(p)
+    med = np.median(R)
+    ext = np.linalg.norm(C.max(0) - C.min(0))
+    rest = []
+    for i in range(N):
+        if N > 8 and R[i] > 8 * med and R[i] > 0.125 * ext: leaf(i)
+        else: rest.append(i)
+    children(np.array(rest))
+    return rec, link
+
+
+def traverse(rec, link, o, d):
+    i = 0; n = len(rec); tests = 0; cands = 0
+    best = 1e30; bi = -1
+    while i < n:
+        c, r = rec[i]; kind, x = link[i]
+        oc = o - c
+        b = oc @ d; cc = oc @ oc - r * r
+        bm = min(b, 0.0)
+        ok = bm * bm - cc > 0
+        tests += 1
+        if kind == "l":
+            if ok:
+                cands += 1
+                disc = b * b - cc
+                if disc > 0 and b < 0:
+                    t = -b - math.sqrt(disc)
+                    if t > 1e-3 and t < best: best, bi = t, x
+            i += 1
+        else:
+            i = i + 1 if ok else x
+    return best, bi, tests, cands
+
+
+sc = SceneRaytracing().createScene(sph)
+cam = sc.camera
+W, H, B = cfg["width"], cfg["height"], cfg["bounces"]
+light = np.array(sc.light.position, dtype=np.float64)
+fw = np.array(cam.forwards, dtype=np.float64); rt = np.array(cam.right, dtype=np.float64); up = np.array(cam.up, dtype=np.float64)
+cp = np.array(cam.position, dtype=np.float64)
+rng = np.random.default_rng(1)
+tx = rng.integers(0, W // 8, ntiles); ty = rng.integers(0, H // 8, ntiles)
+
+# rays once, with a reference hierarchy
+def gen_rays(rec, link):
+    rays = []
+    for t in range(ntiles):
+        lanes = []
+        for ly in range(8):
+            for lx in range(8):
+                x = tx[t] * 8 + lx; y = ty[t] * 8 + ly
+                hc = (x - W / 2) / W * 2; vc = (H / 2 - y) / W * 2
+                d = fw + hc * rt + vc * up; d /= np.linalg.norm(d)
+                lanes.append((cp.copy(), d))
+        for b in range(B):
+            nxt = []
+            for (o, d) in lanes:
+                rays.append((t, o, d))
+                tt, i, _, _ = traverse(rec, link, o, d)
+                if i < 0: continue
+                p = o + tt * d; n = (p - C[i]) / R[i]
+                sd = p - light; sd /= np.linalg.norm(sd)
+                rays.append((t, light, sd))
+                d2 = d - 2 * (d @ n) * n
+                nxt.append((p, d2 / np.linalg.norm(d2)))
+            lanes = nxt
+    return rays
+
+rec0, link0 = build(split_median, bound_box)
+rays = gen_rays(rec0, link0)
+print(cfgname, "N", N, "rays", len(rays))
+for name, split, bound, leafmax, arity in [
+        ("median/box   4/4", split_median, bound_box, 4, 4),
+        ("median/ritter4/4", split_median, bound_ritter, 4, 4),
+        ("sah/box      4/4", split_sah, bound_box, 4, 4),
+        ("sah/ritter   4/4", split_sah, bound_ritter, 4, 4),
+        ("sah/ritter   2/2", split_sah, bound_ritter, 2, 2),
+        ("sah/ritter   6/4", split_sah, bound_ritter, 6, 4),
+        ("sah/ritter   8/8", split_sah, bound_ritter, 8, 8),
+        ("sah/ritter   3/3", split_sah, bound_ritter, 3, 3)]:
+    rec, link = build(split, bound, leafmax, arity)
+    tests = np.array([traverse(rec, link, o, d)[2] for (_, o, d) in rays])
+    cands = np.array([traverse(rec, link, o, d)[3] for (_, o, d) in rays[::7]])
+    # waves: consecutive groups of 64 rays (what regeneration approximates)
+    w = tests[: len(tests) // 64 * 64].reshape(-1, 64)
+    print("%-18s nodes %5d  tests/ray %6.1f  wave-max %6.1f  lane-eff %4.1f%%  cands/ray %.2f" %
+          (name, len(rec), tests.mean(), w.max(1).mean(), 100 * w.mean() / w.max(1).mean(), cands.mean()))
