@@ -66,25 +66,64 @@ struct Builder {
         out_link.push_back(0x80000000u | sphere);
     }
 
-    // longest axis of the centres' box, median split (ties by sphere index: deterministic)
+    // Splits ids[lo,hi) in two.  Up to 32768 members: the position, over all three axes, that
+    // minimises  sum over both sides of (squared diagonal of the members' box) * count  -- a
+    // surface-area heuristic with the box diagonal as the proxy for the bounding sphere
+    // (17 % fewer node tests per ray than the median split on the BASELINE scenes,
+    // tools/bvh_sim.py).  Larger ranges: median of the longest axis.  Ties by sphere index.
     uint32_t split2(uint32_t lo, uint32_t hi) {
-        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t k = lo; k < hi; ++k)
-            for (int a = 0; a < 3; ++a) {
-                const double v = cx(ids[k], a);
-                mn[a] = std::min(mn[a], v); mx[a] = std::max(mx[a], v);
+        const uint32_t n = hi - lo;
+        auto by_axis = [&](int ax) {
+            return [this, ax](uint32_t a, uint32_t b) {
+                const double va = cx(a, ax), vb = cx(b, ax);
+                return va < vb || (va == vb && a < b);
+            };
+        };
+        if (n > 32768u) {
+            double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t k = lo; k < hi; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    const double v = cx(ids[k], a);
+                    mn[a] = std::min(mn[a], v); mx[a] = std::max(mx[a], v);
+                }
+            int ax = 0;
+            if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+            if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+            const uint32_t mid = lo + n / 2u;
+            std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, by_axis(ax));
+            return mid;
+        }
+        double best = INFINITY;
+        int best_ax = 0;
+        uint32_t best_k = n / 2u;
+        std::vector<uint32_t> order(n);
+        std::vector<double> suffix(n);
+        for (int ax = 0; ax < 3; ++ax) {
+            std::copy(ids.begin() + lo, ids.begin() + hi, order.begin());
+            std::sort(order.begin(), order.end(), by_axis(ax));
+            double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            auto grow = [&](uint32_t i) {
+                double d2 = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    mn[a] = std::min(mn[a], cx(i, a) - rad(i));
+                    mx[a] = std::max(mx[a], cx(i, a) + rad(i));
+                    d2 += (mx[a] - mn[a]) * (mx[a] - mn[a]);
+                }
+                return d2;
+            };
+            for (uint32_t k = n; k-- > 1u;) suffix[k] = grow(order[k]) * (double)(n - k);   // members k..n-1
+            for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+            for (uint32_t k = 1; k < n; ++k) {                                              // members 0..k-1 | k..n-1
+                const double cost = grow(order[k - 1u]) * (double)k + suffix[k];
+                if (cost < best) { best = cost; best_ax = ax; best_k = k; }
             }
-        int ax = 0;
-        if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
-        if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
-        const uint32_t mid = lo + (hi - lo) / 2u;
-        std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [&](uint32_t a, uint32_t b) {
-            const double va = cx(a, ax), vb = cx(b, ax);
-            return va < vb || (va == vb && a < b);
-        });
-        return mid;
+        }
+        std::sort(ids.begin() + lo, ids.begin() + hi, by_axis(best_ax));
+        return lo + best_k;
     }
 
+    // bounding sphere of ids[lo,hi): centre of the members' box, then shrink-wrapped -- the centre
+    // moves towards the farthest member while that reduces the radius
     void bound(uint32_t lo, uint32_t hi, float out[4]) {
         double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (uint32_t k = lo; k < hi; ++k)
@@ -92,14 +131,33 @@ struct Builder {
                 mn[a] = std::min(mn[a], cx(ids[k], a) - rad(ids[k]));
                 mx[a] = std::max(mx[a], cx(ids[k], a) + rad(ids[k]));
             }
-        const float C[3] = {(float)(0.5 * (mn[0] + mx[0])), (float)(0.5 * (mn[1] + mx[1])), (float)(0.5 * (mn[2] + mx[2]))};
-        double R = 0.0;
-        for (uint32_t k = lo; k < hi; ++k) {
-            const uint32_t i = ids[k];
-            const double dx = cx(i, 0) - C[0], dy = cx(i, 1) - C[1], dz = cx(i, 2) - C[2];
-            const double r = rad(i);
-            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + r);
+        auto radius_at = [&](const double P[3], uint32_t& far) {
+            double R = -1.0;
+            for (uint32_t k = lo; k < hi; ++k) {
+                const uint32_t i = ids[k];
+                const double dx = cx(i, 0) - P[0], dy = cx(i, 1) - P[1], dz = cx(i, 2) - P[2];
+                const double d = std::sqrt(dx * dx + dy * dy + dz * dz) + rad(i);
+                if (d > R) { R = d; far = i; }
+            }
+            return R;
+        };
+        double P[3] = {0.5 * (mn[0] + mx[0]), 0.5 * (mn[1] + mx[1]), 0.5 * (mn[2] + mx[2])};
+        uint32_t far = ids[lo];
+        double Rp = radius_at(P, far);
+        for (int it = 0; it < 32; ++it) {
+            const double s[3] = {cx(far, 0) - P[0], cx(far, 1) - P[1], cx(far, 2) - P[2]};
+            const double len = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+            if (!(len > 1e-12)) break;
+            const double Q[3] = {P[0] + s[0] / len * 0.05 * Rp, P[1] + s[1] / len * 0.05 * Rp, P[2] + s[2] / len * 0.05 * Rp};
+            uint32_t far_q = far;
+            const double Rq = radius_at(Q, far_q);
+            if (!(Rq < Rp)) break;
+            P[0] = Q[0]; P[1] = Q[1]; P[2] = Q[2]; Rp = Rq; far = far_q;
         }
+        const float C[3] = {(float)P[0], (float)P[1], (float)P[2]};   // the record stores the centre in fp32:
+        const double Cd[3] = {C[0], C[1], C[2]};                       // the radius is taken about THAT point
+        uint32_t unused = 0;
+        double R = radius_at(Cd, unused);
         R *= 1.16;            // sigma, see the header
         const double c2 = (double)C[0] * C[0] + (double)C[1] * C[1] + (double)C[2] * C[2];
         const double k = c2 * (1.0 - (double)RT_FILTER_EPS) - R * R * (1.0 + (double)RT_FILTER_KAPPA);
@@ -119,15 +177,25 @@ struct Builder {
         out_link[me] = (uint32_t)out_link.size();       // skip link: first node after this subtree
     }
 
-    // up to four children: two median splits
+    // up to four children: the largest part is split until there are four
     void children(uint32_t lo, uint32_t hi) {
         if (hi - lo <= 4u) {
             for (uint32_t k = lo; k < hi; ++k) leaf(ids[k]);
             return;
         }
-        const uint32_t mid = split2(lo, hi);
-        const uint32_t q1 = split2(lo, mid), q3 = split2(mid, hi);
-        emit(lo, q1); emit(q1, mid); emit(mid, q3); emit(q3, hi);
+        uint32_t cut[5] = {lo, hi, 0, 0, 0};     // sorted part boundaries
+        int parts = 1;
+        while (parts < 4) {
+            int big = 0;
+            for (int j = 1; j < parts; ++j)
+                if (cut[j + 1] - cut[j] > cut[big + 1] - cut[big]) big = j;
+            if (cut[big + 1] - cut[big] < 2u) break;
+            const uint32_t mid = split2(cut[big], cut[big + 1]);
+            for (int j = parts; j > big; --j) cut[j + 1] = cut[j];
+            cut[big + 1] = mid;
+            ++parts;
+        }
+        for (int j = 0; j < parts; ++j) emit(cut[j], cut[j + 1]);
     }
 };
 
@@ -273,14 +341,17 @@ __global__ __launch_bounds__(64 * WAVES) void bvh_pixels(const RtFrameArgs A) {
     float4* sR = lds;
     uint32_t* sL = reinterpret_cast<uint32_t*>(lds + (NLDS ? n4 : 0u));
     uint32_t* lists = sL + (NLDS ? n4 : 0u);
-    if (NLDS) {
+    if (NLDS)
         for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) { sR[i] = A.bvh_rec[i]; sL[i] = A.bvh_link[i]; }
-        __syncthreads();
-    }
     const float4* R = NLDS ? sR : A.bvh_rec;
     const uint32_t* L = NLDS ? sL : A.bvh_link;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* slot = lists + wave * (uint32_t)(CAP * 64) + lane;
+    // rgba8unorm -> float table for the cube map texels: the reference's x / 255 division done
+    // 256 times per workgroup instead of 12 times per sample
+    float* lut = reinterpret_cast<float*>(lists + WAVES * CAP * 64);
+    for (uint32_t i = threadIdx.x; i < 256u; i += 64 * WAVES) lut[i] = (float)i / 255.0f;
+    __syncthreads();
 
     const Scene sc = unpack_scene(A);
     const uint32_t tiles_x = (A.W + 7u) / 8u;
@@ -290,8 +361,8 @@ __global__ __launch_bounds__(64 * WAVES) void bvh_pixels(const RtFrameArgs A) {
 
     // per-lane path state (RK:101-144 unrolled into a state machine)
     bool active = false, shadow = false;
-    uint32_t opix = 0, px = 0, py = 0, bounce = 0, nrays = 0;
-    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(1, 1, 1);
+    uint32_t opix = 0, bounce = 0, nrays = 0;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(1, 1, 1), fog = V(0, 0, 0);
     v3 normal = V(0, 0, 1), sdir = V(0, 0, 1), albedo = V(0, 0, 0);
     float dist = 0.0f, affect = 1.0f, sum = 0.0f, distance = 1.0f;
 
@@ -315,9 +386,9 @@ __global__ __launch_bounds__(64 * WAVES) void bvh_pixels(const RtFrameArgs A) {
                 const uint32_t x = tx * 8u + (l & 7u), row = l >> 3;
                 const uint32_t y = (A.tile_first + ty * A.tile_step) * 8u + row;
                 if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
-                    px = x; py = y;
                     opix = (ty * 8u + row) * A.W + x;
                     ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
+                    if (sc.bounces == 0u) fog = scale(sc.minIntensity, cube_sample(A, rd, lut));   // no ray will be cast
                     color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
                     affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
                     shadow = false;
@@ -343,8 +414,12 @@ __global__ __launch_bounds__(64 * WAVES) void bvh_pixels(const RtFrameArgs A) {
             const float next = affect + sum;                             // RK:120
             if (!shadow) {
                 if (bounce == 0u) dist = idx >= 0 ? t : 0.0f;            // RK:116-118
+                // One sky sample serves RK:124 (the ray missed) and RK:93-96 (the fog colour of
+                // the pixel = the sky along the PRIMARY direction, which is rd at bounce 0).
+                v3 sky = V(0, 0, 0);
+                if (bounce == 0u || idx < 0) sky = scale(sc.minIntensity, cube_sample(A, rd, lut));
+                if (bounce == 0u) fog = sky;
                 if (idx < 0) {                                           // RK:122-126
-                    const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
                     color = divs(add(scale(sum, color), scale(affect, sky)), next);
                     finished = true;
                 } else {
@@ -371,8 +446,7 @@ __global__ __launch_bounds__(64 * WAVES) void bvh_pixels(const RtFrameArgs A) {
             }
         }
         if (finished) {
-            const v3 dir0 = primary_dir(A, sc, px, py);
-            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, dir0, color, dist);   // RK:91-98
+            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel_sky(fog, color, dist);   // RK:91-98
             active = false;
         }
     }
@@ -403,9 +477,10 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     const size_t n4 = ((size_t)a.bvh_nodes + 4u) & ~(size_t)3u;
     const size_t nodes = n4 * 20u;
     const size_t cap = 160u * 1024u;
-    if (nodes + 8u * CAP * 256u <= cap / 2u) return launch_bvh_as<8, SGN, true, CAP>(a, nodes + 8u * CAP * 256u, s);
-    if (nodes + 16u * CAP * 256u <= cap)     return launch_bvh_as<16, SGN, true, CAP>(a, nodes + 16u * CAP * 256u, s);
-    return launch_bvh_as<8, SGN, false, CAP>(a, 8u * CAP * 256u, s);
+    constexpr size_t lut = 1024u;
+    if (nodes + 8u * CAP * 256u + lut <= cap / 2u) return launch_bvh_as<8, SGN, true, CAP>(a, nodes + 8u * CAP * 256u + lut, s);
+    if (nodes + 16u * CAP * 256u + lut <= cap)     return launch_bvh_as<16, SGN, true, CAP>(a, nodes + 16u * CAP * 256u + lut, s);
+    return launch_bvh_as<8, SGN, false, CAP>(a, 8u * CAP * 256u + lut, s);
 }
 
 }  // namespace rtk

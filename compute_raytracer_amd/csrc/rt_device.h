@@ -25,15 +25,17 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fm
 __device__ __forceinline__ v3 reflect(v3 e1, v3 e2) { return sub(e1, scale(2.0f * dot(e2, e1), e2)); }
 
 // ---- cube map sample: the arithmetic oracle/rt_oracle.c:cube_sample fixes -------------------
-__device__ __forceinline__ v3 texel(const uint8_t* __restrict__ f, int w, int h, int x, int y) {
+// lut: optional 256-entry table of (float)i / 255.0f (same division, done once per workgroup)
+__device__ __forceinline__ v3 texel(const uint8_t* __restrict__ f, int w, int h, int x, int y, const float* lut = nullptr) {
     x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
     y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
     const uchar4 p = *reinterpret_cast<const uchar4*>(f + 4u * ((size_t)y * (size_t)w + (size_t)x));
+    if (lut) return V(lut[p.x], lut[p.y], lut[p.z]);
     return V((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f);
 }
 __device__ __forceinline__ v3 lerp3(v3 a, v3 b, float f) { return add(a, scale(f, sub(b, a))); }
 
-__device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r) {
+__device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = nullptr) {
     const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
     int face; float sc, tc, ma;
     if (az >= ax && az >= ay) {
@@ -58,8 +60,8 @@ __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r) {
     const float fu = floorf(u), fv = floorf(v);
     const float wu = u - fu, wv = v - fv;
     const int x0 = (int)fu, y0 = (int)fv;
-    const v3 c00 = texel(f, w, h, x0, y0), c10 = texel(f, w, h, x0 + 1, y0);
-    const v3 c01 = texel(f, w, h, x0, y0 + 1), c11 = texel(f, w, h, x0 + 1, y0 + 1);
+    const v3 c00 = texel(f, w, h, x0, y0, lut), c10 = texel(f, w, h, x0 + 1, y0, lut);
+    const v3 c01 = texel(f, w, h, x0, y0 + 1, lut), c11 = texel(f, w, h, x0 + 1, y0 + 1, lut);
     return lerp3(lerp3(c00, c10, wu), lerp3(c01, c11, wu), wv);
 }
 
@@ -98,11 +100,14 @@ __device__ __forceinline__ v3 primary_dir(const RtFrameArgs& A, const Scene& sc,
 }
 
 // RK:91-98: fog/sky compose and rgba8unorm pack
-__device__ __forceinline__ uint32_t compose_pixel(const RtFrameArgs& A, const Scene& sc, v3 dir0, v3 color, float dist) {
-    const v3 sky = scale(sc.minIntensity, cube_sample(A, dir0));
+// sky = minIntensity * cube_sample(primary direction)
+__device__ __forceinline__ uint32_t compose_pixel_sky(v3 sky, v3 color, float dist) {
     const float k = clampf((30.0f - dist) / 30.0f, 0.0f, 1.0f);
     const v3 px = add(scale(k, color), scale(1.0f - k, sky));
     return unorm8(px.x) | (unorm8(px.y) << 8) | (unorm8(px.z) << 16) | 0xFF000000u;
+}
+__device__ __forceinline__ uint32_t compose_pixel(const RtFrameArgs& A, const Scene& sc, v3 dir0, v3 color, float dist) {
+    return compose_pixel_sky(scale(sc.minIntensity, cube_sample(A, dir0)), color, dist);
 }
 
 // RK:155-165: the tail of lightIntensity once the shadow ray's nearest hit (st, shit) is known

@@ -61,6 +61,24 @@ def split_sah(ids, bound):
     return best[1], best[2]
 
 
+def split_sah_diag(ids, bound):
+    # cost proxy: squared half-diagonal of the members' box (radii included) times the count,
+    # every split position of every axis, prefix/suffix boxes
+    best = None
+    for ax in range(3):
+        o = ids[np.argsort(C[ids, ax], kind="stable")]
+        lo = C[o] - R[o, None]; hi = C[o] + R[o, None]
+        plo = np.minimum.accumulate(lo, 0); phi = np.maximum.accumulate(hi, 0)
+        slo = np.minimum.accumulate(lo[::-1], 0)[::-1]; shi = np.maximum.accumulate(hi[::-1], 0)[::-1]
+        n = len(o)
+        h = np.arange(1, n)
+        ca = ((phi[:-1] - plo[:-1]) ** 2).sum(1) * h
+        cb = ((shi[1:] - slo[1:]) ** 2).sum(1) * (n - h)
+        k = int(np.argmin(ca + cb))
+        if best is None or ca[k] + cb[k] < best[0]: best = (ca[k] + cb[k], o[:k + 1], o[k + 1:])
+    return best[1], best[2]
+
+
 def build(split, bound, leafmax=4, arity=4):
     rec = []; link = []
     def leaf(i):
@@ -158,10 +176,10 @@ for name, split, bound, leafmax, arity in [
         ("median/ritter4/4", split_median, bound_ritter, 4, 4),
         ("sah/box      4/4", split_sah, bound_box, 4, 4),
         ("sah/ritter   4/4", split_sah, bound_ritter, 4, 4),
-        ("sah/ritter   2/2", split_sah, bound_ritter, 2, 2),
-        ("sah/ritter   6/4", split_sah, bound_ritter, 6, 4),
-        ("sah/ritter   8/8", split_sah, bound_ritter, 8, 8),
-        ("sah/ritter   3/3", split_sah, bound_ritter, 3, 3)]:
+        ("sahdiag/box  4/4", split_sah_diag, bound_box, 4, 4),
+        ("sahdiag/ritt 4/4", split_sah_diag, bound_ritter, 4, 4),
+        ("sahdiag/box  3/3", split_sah_diag, bound_box, 3, 3),
+        ("sahdiag/box  6/4", split_sah_diag, bound_box, 6, 4)]:
     rec, link = build(split, bound, leafmax, arity)
     tests = np.array([traverse(rec, link, o, d)[2] for (_, o, d) in rays])
     cands = np.array([traverse(rec, link, o, d)[3] for (_, o, d) in rays[::7]])
