@@ -445,8 +445,12 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         fa.signed_filter = (reach == reach && 2.0 * reach * 7.3e-7 < 5.0e-4) ? 1u : 0u;
     }
     const bool filter_ok = reach < 1048576.0;
-    // variant 4: bounding-sphere hierarchy, (re)built when the spheres changed
-    const bool use_bvh = !tri && c->mode == RT_MODE_FAST && c->variant == 4 && filter_ok && c->n > 0;
+    // Fast mode renders through the bounding-sphere hierarchy (rt_bvh.hip) from 128 spheres on
+    // (default, variant 0; measured crossover against the brute-force kernels ~100 spheres) or
+    // whenever variant 4 asks for it; variant 5 is the brute-force default, 1-3 its forms.  The
+    // hierarchy is (re)built on the host when the spheres changed.
+    const bool use_bvh = !tri && c->mode == RT_MODE_FAST && filter_ok && c->n > 0 &&
+                         (c->variant == 4 || (c->variant == 0 && c->n >= 128u));
     fa.bvh_rec = nullptr; fa.bvh_link = nullptr; fa.bvh_nodes = 0;
     if (use_bvh) {
         if (!c->bvh_valid) {
@@ -476,7 +480,7 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     fa.queue_cap = (uint32_t)c->queue_cap;
     RtLaunchCfg cfg;
     cfg.mode = filter_ok ? c->mode : (int)RT_MODE_STRICT;
-    cfg.variant = c->variant;
+    cfg.variant = (c->variant == 4 || c->variant == 5) ? 0 : c->variant;   // rt_kernels.hip numbers its default 0
 
     RT_HIP(hipEventRecord(c->ev_k0[slot], s));
     if (tri) {

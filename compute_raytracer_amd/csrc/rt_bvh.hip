@@ -289,6 +289,10 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
 
     auto drain = [&]() {
         for (uint32_t* rp = slot; __ballot(rp < wp) != 0ull; rp += 64) {
+#ifdef RT_BVH_COUNT
+            if (RT_BVH_COUNT == 4) g_steps += (threadIdx.x & 63u) == 0u ? 1u : 0u;     // drain iterations (wave)
+            if (RT_BVH_COUNT == 5) g_steps += rp < wp ? 1u : 0u;                       // candidates evaluated (lane)
+#endif
             if (rp < wp) {
                 const int si = (int)(*rp & 0x7FFFFFFFu);
                 const float4 g = geo[si];
@@ -404,6 +408,7 @@ __global__ __launch_bounds__(64 * WAVES) void bvh_pixels(const RtFrameArgs A) {
         const bool tracing = active && !finished;
         float t; int idx;
 #ifdef RT_BVH_COUNT
+        if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
         trace_bvh<SGN, CAP>(R, L, n, A.geo, slot, tracing, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
         if (tracing) {
 #else

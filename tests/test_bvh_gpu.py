@@ -1,4 +1,5 @@
-"""Variant 4 (rt_bvh.hip): sphere scenes through the bounding-sphere hierarchy.  The hierarchy
+"""rt_bvh.hip: sphere scenes through the bounding-sphere hierarchy (the fast-mode default from
+128 spheres on; variant 4 forces it for any sphere count).  The hierarchy
 only decides which spheres are evaluated; every pixel must still be the oracle's, bit for bit:
 golden frames of the BASELINE configs, random scenes over many orders of magnitude of size and
 offset (the node radii carry a slack derived from the scene's reach), degenerate scenes (one
@@ -101,3 +102,29 @@ def test_camera_leaves_the_reach_the_hierarchy_was_built_for(oracle):
         assert np.array_equal(img, ref), (step, diff_stats(img, ref))
         assert r.stats()["rays"] == rays
     r.close()
+
+
+def test_brute_force_pipeline_still_matches_golden():
+    """variant 5 = the brute-force default (first_bounce + trace_paths at C3)."""
+    meta = json.load(open(os.path.join(GOLDEN, "frames.json")))["C3"]
+    cfg, scene = config_inputs("C3")
+    img, st = gpu_render(scene, cfg["width"], cfg["height"], cfg["bounces"], strict=False, variant=5)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == meta["sha256"] and st["rays"] == meta["rays"]
+
+
+@pytest.mark.parametrize("variant", [0, 4, 5])
+def test_scene_beyond_the_filter_range_is_rendered_literally(oracle, variant):
+    """|coordinates| >= 2^20: the 2^40-scaled filter arithmetic could overflow, so fast mode hands
+    the frame to the literal kernel; the pixels are still the oracle's."""
+    off = np.array([3.0e6, -2.0e6, 1.5e6])
+    spheres = [rt.Sphere(off + np.array([i * 3.0 - 9.0, 1.0, -14.0]), 1.2, [0.3 + 0.1 * i, 0.6, 0.8]) for i in range(7)]
+    spheres += [rt.Sphere(off + np.array([0.0, -2000.0, -14.0]), 1998.0, [0.8, 0.8, 0.8])]
+    spheres *= 20                              # 160 spheres: above the hierarchy threshold
+    scene = rt.SceneRaytracing().createScene(spheres)
+    scene.camera.position = list(off + np.array([0.0, 2.0, 4.0]))
+    scene.camera.update()
+    scene.light.position = list(off + np.array([0.0, 9.0, -6.0]))
+    ref, _, rays = oracle_render(oracle, scene, 96, 64, 3)
+    img, st = gpu_render(scene, 96, 64, 3, strict=False, variant=variant)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays

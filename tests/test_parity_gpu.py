@@ -146,7 +146,7 @@ def test_more_spheres_than_fit_in_lds(oracle):
         assert st["rays"] == rays and st["spheres"] == 6000
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_kernel_variants_agree(oracle, variant):
     cfg, scene = config_inputs("C2", width=480, height=272)
     ref, _, rays = oracle_render(oracle, scene, 480, 272, 4)

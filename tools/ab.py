@@ -16,9 +16,12 @@ def main():
     ap.add_argument("--variants", default="1,2,3,4")
     ap.add_argument("--modes", default="fast,strict")
     ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--spheres", type=int, default=0, help="override the sphere count of the config")
     a = ap.parse_args()
     for name in a.configs:
-        cfg = rt.BASELINE_CONFIGS[name]
+        cfg = dict(rt.BASELINE_CONFIGS[name])
+        if a.spheres:
+            cfg["spheres"] = a.spheres
         scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
         for mode in a.modes.split(","):
             for v in [int(x) for x in a.variants.split(",")]:

@@ -111,6 +111,7 @@ def build(split, bound, leafmax=4, arity=4):
     return rec, link
 
 
+TCULL = False
 def traverse(rec, link, o, d):
     i = 0; n = len(rec); tests = 0; cands = 0
     best = 1e30; bi = -1
@@ -120,6 +121,8 @@ def traverse(rec, link, o, d):
         b = oc @ d; cc = oc @ oc - r * r
         bm = min(b, 0.0)
         ok = bm * bm - cc > 0
+        if TCULL and ok and cc > 0 and best < 1e29:
+            ok = (-b - math.sqrt(b * b - cc)) < best        # entry distance beyond the nearest hit so far
         tests += 1
         if kind == "l":
             if ok:
@@ -171,7 +174,8 @@ def gen_rays(rec, link):
 rec0, link0 = build(split_median, bound_box)
 rays = gen_rays(rec0, link0)
 print(cfgname, "N", N, "rays", len(rays))
-for name, split, bound, leafmax, arity in [
+import itertools
+for (name, split, bound, leafmax, arity), tc in itertools.product([
         ("median/box   4/4", split_median, bound_box, 4, 4),
         ("median/ritter4/4", split_median, bound_ritter, 4, 4),
         ("sah/box      4/4", split_sah, bound_box, 4, 4),
@@ -179,11 +183,12 @@ for name, split, bound, leafmax, arity in [
         ("sahdiag/box  4/4", split_sah_diag, bound_box, 4, 4),
         ("sahdiag/ritt 4/4", split_sah_diag, bound_ritter, 4, 4),
         ("sahdiag/box  3/3", split_sah_diag, bound_box, 3, 3),
-        ("sahdiag/box  6/4", split_sah_diag, bound_box, 6, 4)]:
+        ("sahdiag/box  6/4", split_sah_diag, bound_box, 6, 4)][5:6], [False, True]):
+    TCULL = tc
     rec, link = build(split, bound, leafmax, arity)
     tests = np.array([traverse(rec, link, o, d)[2] for (_, o, d) in rays])
     cands = np.array([traverse(rec, link, o, d)[3] for (_, o, d) in rays[::7]])
     # waves: consecutive groups of 64 rays (what regeneration approximates)
     w = tests[: len(tests) // 64 * 64].reshape(-1, 64)
-    print("%-18s nodes %5d  tests/ray %6.1f  wave-max %6.1f  lane-eff %4.1f%%  cands/ray %.2f" %
+    print("tcull" if tc else "     ", "%-18s nodes %5d  tests/ray %6.1f  wave-max %6.1f  lane-eff %4.1f%%  cands/ray %.2f" %
           (name, len(rec), tests.mean(), w.max(1).mean(), 100 * w.mean() / w.max(1).mean(), cands.mean()))
