@@ -337,8 +337,11 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
 
 // ---- kernel ---------------------------------------------------------------------------------------------
 // NLDS: node records and links staged in LDS (else read from global memory / L2: any scene size).
+// 8-wave workgroups are held to 80 VGPRs (6 waves per SIMD, three workgroups per CU): the walk is a
+// chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
+// workgroups serve scenes whose nodes leave room for one workgroup per CU only (4 waves per SIMD).
 template <int WAVES, bool SGN, bool NLDS, int CAP>
-__global__ __launch_bounds__(64 * WAVES) void bvh_pixels(const RtFrameArgs A) {
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
     const uint32_t n4 = (n + 4u) & ~3u;
@@ -483,7 +486,7 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     const size_t nodes = n4 * 20u;
     const size_t cap = 160u * 1024u;
     constexpr size_t lut = 1024u;
-    if (nodes + 8u * CAP * 256u + lut <= cap / 2u) return launch_bvh_as<8, SGN, true, CAP>(a, nodes + 8u * CAP * 256u + lut, s);
+    if (nodes + 8u * CAP * 256u + lut <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP>(a, nodes + 8u * CAP * 256u + lut, s);
     if (nodes + 16u * CAP * 256u + lut <= cap)     return launch_bvh_as<16, SGN, true, CAP>(a, nodes + 16u * CAP * 256u + lut, s);
     return launch_bvh_as<8, SGN, false, CAP>(a, 8u * CAP * 256u + lut, s);
 }
