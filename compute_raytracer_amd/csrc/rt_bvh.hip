@@ -231,6 +231,17 @@ uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4
     return nodes;
 }
 
+// Lanes still walking below which a wave suspends the walk (0: never).  Measured (tools/ab.py,
+// same box): C3 3.93 / 3.51 / 3.36 / 3.40 / 3.44 ms and C5 40.7 / 32.5 / 29.1 / 27.8 / 27.3 ms for
+// 0 / 8 / 16 / 24 / 32: the larger the scene, the longer the walk relative to the shading a
+// suspension repeats.
+#ifndef RT_BVH_TAIL_SMALL
+#define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres) */
+#endif
+#ifndef RT_BVH_TAIL_LARGE
+#define RT_BVH_TAIL_LARGE 32   /* 16-wave workgroups and the global-memory form */
+#endif
+
 namespace rtk {
 
 // ---- device: leaf records = the filter records prep_spheres wrote ------------------------------------
@@ -264,11 +275,16 @@ __device__ __forceinline__ void exact_any_order(v3 center, float r2, int s, v3 o
     }
 }
 
-// Nearest hit of the ray (o, d) of every ACTIVE lane.  R/L: node records and links (LDS or
-// global), n: node count, geo: exact {c, r*r}.  slot: this lane's candidate column ([k*64]).
-template <bool SGN, int CAP>
+// Advances the walk of every lane's ray (o, d).  R/L: node records and links (LDS or global),
+// n: node count, geo: exact {c, r*r}.  slot: this lane's candidate column ([k*64]).
+// i: the lane's position in the node array, in and out: 0 starts a ray (the caller then also sets
+// nearest = 9999, idx = -1, RK:172), n = no ray / walk complete.  TAIL > 0: once some lanes have
+// completed and fewer than TAIL lanes are still walking, the call returns; the stragglers resume
+// in the next call, next to the fresh rays of the lanes that completed -- the long tail of a
+// wave's slowest rays no longer holds 64 lanes for a handful.
+template <bool SGN, int CAP, int TAIL>
 __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
-                                          const float4* __restrict__ geo, uint32_t* slot, bool active, v3 o, v3 d,
+                                          const float4* __restrict__ geo, uint32_t* slot, uint32_t& i, v3 o, v3 d,
                                           float& nearest, int& idx
 #ifdef RT_BVH_COUNT
                                           , uint32_t& steps_acc
@@ -283,8 +299,6 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     const v3 m = V(-2.0f * os.x, -2.0f * os.y, -2.0f * os.z);
     const float p = dot(h, os);
     const float q = dot(os, os) * (1.0f - RT_FILTER_EPS);
-    nearest = 9999.0f;                   // RK:172
-    idx = -1;
     uint32_t* wp = slot;                 // next free entry of this lane's candidate column
 
     auto drain = [&]() {
@@ -305,9 +319,9 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     // node n is a sentinel that never passes and links to itself: a lane that is done (or has
     // no ray) idles on it without an exec-mask test per step; the wave leaves the loop when
     // every lane sits there.  Two steps per trip halve the loop overhead.
-    auto step = [&](uint32_t i) -> uint32_t {
-        const float4 g = R[i];
-        const uint32_t lk = L[i];
+    auto step = [&](uint32_t j) -> uint32_t {
+        const float4 g = R[j];
+        const uint32_t lk = L[j];
         const float b = fnma_vvv(h.z, g.z, fnma_vvv(h.y, g.y, fnma_vvv(h.x, g.x, p)));
         const float cp = fma_vvv(m.z, g.z, fma_vvv(m.y, g.y, fma_vvv(m.x, g.x, g.w)));
         const float bm = SGN ? min0(b) : b;
@@ -317,10 +331,13 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
             *wp = lk;
             wp += 64;
         }
-        return (leaf || pass) ? i + 1u : lk;
+        return (leaf || pass) ? j + 1u : lk;
     };
-    uint32_t i = active ? 0u : n;
-    while (__ballot(i != n) != 0ull) {
+    const uint64_t walking0 = __ballot(i != n);
+    for (;;) {
+        const uint64_t walking = __ballot(i != n);
+        if (walking == 0ull) break;
+        if (TAIL > 0 && walking != walking0 && __popcll(walking) < TAIL) break;
 #ifdef RT_BVH_COUNT   // development statistics: 1 = wave iterations, 2 = lane tests (reported as "rays")
         if (RT_BVH_COUNT == 1) g_steps += (threadIdx.x & 63u) == 0u ? 2u : 0u;
         if (RT_BVH_COUNT == 2) g_steps += i != n ? 1u : 0u;
@@ -340,7 +357,7 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
 // 8-wave workgroups are held to 80 VGPRs (6 waves per SIMD, three workgroups per CU): the walk is a
 // chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
 // workgroups serve scenes whose nodes leave room for one workgroup per CU only (4 waves per SIMD).
-template <int WAVES, bool SGN, bool NLDS, int CAP>
+template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
@@ -372,6 +389,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(1, 1, 1), fog = V(0, 0, 0);
     v3 normal = V(0, 0, 1), sdir = V(0, 0, 1), albedo = V(0, 0, 0);
     float dist = 0.0f, affect = 1.0f, sum = 0.0f, distance = 1.0f;
+    uint32_t node = n;           // position of the lane's current ray in the node array; n: none
+    float t = 9999.0f;           // nearest hit of the current ray so far (RK:172)
+    int idx = -1;
 
     for (;;) {
         // ---- idle lanes take the next pixels ----
@@ -400,6 +420,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                     affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
                     shadow = false;
                     active = true;
+                    node = 0u; t = 9999.0f; idx = -1;            // primary ray
+                    if (sc.bounces == 0u) node = n;              // RK:113: the loop body never runs
                 }
             }
             cur += take;
@@ -407,16 +429,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
         }
         if (__ballot(active) == 0ull) break;
 
-        bool finished = active && sc.bounces == 0u;              // RK:113: the loop body never runs
-        const bool tracing = active && !finished;
-        float t; int idx;
+        bool finished = active && sc.bounces == 0u;
+        const bool walking = node != n;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
-        trace_bvh<SGN, CAP>(R, L, n, A.geo, slot, tracing, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
-        if (tracing) {
+        trace_bvh<SGN, CAP, TAIL>(R, L, n, A.geo, slot, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
+        if (walking && node == n) {
 #else
-        trace_bvh<SGN, CAP>(R, L, n, A.geo, slot, tracing, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
-        if (tracing) {
+        trace_bvh<SGN, CAP, TAIL>(R, L, n, A.geo, slot, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
+        if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
 #endif
             const float next = affect + sum;                             // RK:120
@@ -441,6 +462,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                     sdir = normalize(sub(ro, sc.lightPos));                  // RK:147
                     distance = length(sdir);                                 // RK:148
                     shadow = true;                                           // RK:153 next
+                    node = 0u; t = 9999.0f; idx = -1;                        // shadow ray
                 }
             } else {
                 const float intensity = light_term(sc, ro, normal, sdir, distance, idx >= 0, t);
@@ -451,6 +473,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 ++bounce;
                 shadow = false;
                 finished = bounce >= sc.bounces;                             // RK:113
+                if (!finished) { node = 0u; t = 9999.0f; idx = -1; }         // next reflection ray
             }
         }
         if (finished) {
@@ -461,9 +484,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     count_rays(A.rays, nrays);
 }
 
-template <int WAVES, bool SGN, bool NLDS, int CAP>
+template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
 hipError_t launch_bvh_as(const RtFrameArgs& a, size_t lds, hipStream_t s) {
-    auto k = bvh_pixels<WAVES, SGN, NLDS, CAP>;
+    auto k = bvh_pixels<WAVES, SGN, NLDS, CAP, TAIL>;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -486,9 +509,9 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     const size_t nodes = n4 * 20u;
     const size_t cap = 160u * 1024u;
     constexpr size_t lut = 1024u;
-    if (nodes + 8u * CAP * 256u + lut <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP>(a, nodes + 8u * CAP * 256u + lut, s);
-    if (nodes + 16u * CAP * 256u + lut <= cap)     return launch_bvh_as<16, SGN, true, CAP>(a, nodes + 16u * CAP * 256u + lut, s);
-    return launch_bvh_as<8, SGN, false, CAP>(a, 8u * CAP * 256u + lut, s);
+    if (nodes + 8u * CAP * 256u + lut <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * CAP * 256u + lut, s);
+    if (nodes + 16u * CAP * 256u + lut <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * CAP * 256u + lut, s);
+    return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 8u * CAP * 256u + lut, s);
 }
 
 }  // namespace rtk
