@@ -174,7 +174,7 @@ struct Builder {
         float b[4];
         bound(lo, hi, b);
         std::copy(b, b + 4, out_rec.begin() + 4 * me);
-        out_link[me] = (uint32_t)out_link.size();       // skip link: first node after this subtree
+        out_link[me] = 4u * (uint32_t)out_link.size();  // skip link: first node after this subtree, as 4 * index
     }
 
     // up to four children: the largest part is split until there are four
@@ -227,7 +227,7 @@ uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4
     if (!b.ids.empty()) b.children(0u, (uint32_t)b.ids.size());
     const uint32_t nodes = (uint32_t)link.size();
     rec4.insert(rec4.end(), {0.0f, 0.0f, 0.0f, INFINITY});   // sentinel [nodes]: never passes, links to itself
-    link.push_back(nodes);
+    link.push_back(4u * nodes);
     return nodes;
 }
 
@@ -282,7 +282,7 @@ __device__ __forceinline__ void exact_any_order(v3 center, float r2, int s, v3 o
 // completed and fewer than TAIL lanes are still walking, the call returns; the stragglers resume
 // in the next call, next to the fresh rays of the lanes that completed -- the long tail of a
 // wave's slowest rays no longer holds 64 lanes for a handful.
-template <bool SGN, int CAP, int TAIL>
+template <bool SGN, bool NLDS, int CAP, int TAIL>
 __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
                                           const float4* __restrict__ geo, uint32_t* slot, uint32_t& i, v3 o, v3 d,
                                           float& nearest, int& idx
@@ -299,57 +299,76 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     const v3 m = V(-2.0f * os.x, -2.0f * os.y, -2.0f * os.z);
     const float p = dot(h, os);
     const float q = dot(os, os) * (1.0f - RT_FILTER_EPS);
-    uint32_t* wp = slot;                 // next free entry of this lane's candidate column
+    uint32_t cnt = 0;                    // entries in this lane's candidate column
 
     auto drain = [&]() {
-        for (uint32_t* rp = slot; __ballot(rp < wp) != 0ull; rp += 64) {
+        for (uint32_t k = 0; __ballot(k < cnt) != 0ull; ++k) {
 #ifdef RT_BVH_COUNT
             if (RT_BVH_COUNT == 4) g_steps += (threadIdx.x & 63u) == 0u ? 1u : 0u;     // drain iterations (wave)
-            if (RT_BVH_COUNT == 5) g_steps += rp < wp ? 1u : 0u;                       // candidates evaluated (lane)
+            if (RT_BVH_COUNT == 5) g_steps += k < cnt ? 1u : 0u;                       // candidates evaluated (lane)
 #endif
-            if (rp < wp) {
-                const int si = (int)(*rp & 0x7FFFFFFFu);
+            if (k < cnt) {
+                const int si = (int)(slot[k * 64u] & 0x7FFFFFFFu);
                 const float4 g = geo[si];
                 exact_any_order(V(g.x, g.y, g.z), g.w, si, o, d, fa, ta, nearest, idx);
             }
         }
-        wp = slot;
+        cnt = 0;
     };
 
-    // node n is a sentinel that never passes and links to itself: a lane that is done (or has
-    // no ray) idles on it without an exec-mask test per step; the wave leaves the loop when
-    // every lane sits there.  Two steps per trip halve the loop overhead.
+    // The walk's state is j = 4 * node index (+ the LDS address of the link array when the nodes
+    // are staged in LDS): the address of the node's link, so that read needs no address
+    // arithmetic, the record's address is one v_lshl_add, and the links themselves are stored in
+    // this unit.  Node n is a sentinel that never passes and links to itself: a lane that is done
+    // (or has no ray) idles on it without an exec-mask test per step; the wave leaves the loop
+    // when every lane sits there.  Two steps per trip halve the loop overhead.
+    typedef __attribute__((address_space(3))) const uint32_t* lds_u32;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const f4v* lds_f4;
+    const uint32_t l0 = NLDS ? (uint32_t)(uintptr_t)L : 0u;                       // LDS address of L[0]
+    const uint32_t r0 = NLDS ? (uint32_t)(uintptr_t)R - 4u * l0 : 0u;             // record address = 4 * j + r0
     auto step = [&](uint32_t j) -> uint32_t {
-        const float4 g = R[j];
-        const uint32_t lk = L[j];
+        uint32_t lk;
+        float4 g;
+        if (NLDS) {
+            lk = *(lds_u32)(uintptr_t)j;
+            const f4v gv = *(lds_f4)(uintptr_t)(4u * j + r0);
+            g = make_float4(gv.x, gv.y, gv.z, gv.w);
+        } else {
+            lk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(L) + j);
+            g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R) + 4u * (size_t)j);
+        }
         const float b = fnma_vvv(h.z, g.z, fnma_vvv(h.y, g.y, fnma_vvv(h.x, g.x, p)));
         const float cp = fma_vvv(m.z, g.z, fma_vvv(m.y, g.y, fma_vvv(m.x, g.x, g.w)));
         const float bm = SGN ? min0(b) : b;
         const bool pass = __builtin_fmaf(bm, bm, -q) > cp;
         const bool leaf = (int)lk < 0;
         if (leaf && pass) {
-            *wp = lk;
-            wp += 64;
+            slot[cnt * 64u] = lk;
+            ++cnt;
         }
-        return (leaf || pass) ? j + 1u : lk;
+        return (leaf || pass) ? j + 4u : lk;     // staged links already carry the LDS base
     };
-    const uint64_t walking0 = __ballot(i != n);
+    const uint32_t jn = 4u * n + l0;
+    uint32_t j = 4u * i + l0;
+    const uint64_t walking0 = __ballot(j != jn);
     for (;;) {
-        const uint64_t walking = __ballot(i != n);
+        const uint64_t walking = __ballot(j != jn);
         if (walking == 0ull) break;
-        if (TAIL > 0 && walking != walking0 && __popcll(walking) < TAIL) break;
+        if (TAIL > 0 && walking != walking0 && __builtin_popcount((uint32_t)walking) + __builtin_popcount((uint32_t)(walking >> 32)) < TAIL) break;
 #ifdef RT_BVH_COUNT   // development statistics: 1 = wave iterations, 2 = lane tests (reported as "rays")
         if (RT_BVH_COUNT == 1) g_steps += (threadIdx.x & 63u) == 0u ? 2u : 0u;
-        if (RT_BVH_COUNT == 2) g_steps += i != n ? 1u : 0u;
+        if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
 #endif
-        i = step(i);
+        j = step(j);
 #ifdef RT_BVH_COUNT
-        if (RT_BVH_COUNT == 2) g_steps += i != n ? 1u : 0u;
+        if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
 #endif
-        i = step(i);
-        if (__ballot(wp >= slot + (CAP - 1) * 64) != 0ull) drain();
+        j = step(j);
+        if (__ballot(cnt >= (uint32_t)(CAP - 1)) != 0ull) drain();
     }
     drain();
+    i = (j - l0) >> 2;
 }
 
 // ---- kernel ---------------------------------------------------------------------------------------------
@@ -362,11 +381,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
     const uint32_t n4 = (n + 4u) & ~3u;
-    float4* sR = lds;
-    uint32_t* sL = reinterpret_cast<uint32_t*>(lds + (NLDS ? n4 : 0u));
-    uint32_t* lists = sL + (NLDS ? n4 : 0u);
+    uint32_t* sL = reinterpret_cast<uint32_t*>(lds);                 // links at LDS offset 0 (see trace_bvh)
+    float4* sR = lds + (NLDS ? n4 / 4u : 0u);
+    uint32_t* lists = reinterpret_cast<uint32_t*>(sR + (NLDS ? n4 : 0u));
     if (NLDS)
-        for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) { sR[i] = A.bvh_rec[i]; sL[i] = A.bvh_link[i]; }
+        for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) {
+            sR[i] = A.bvh_rec[i];
+            const uint32_t lk = A.bvh_link[i];      // inner links become LDS addresses of the target's link
+            sL[i] = (int)lk < 0 ? lk : lk + (uint32_t)(uintptr_t)sL;
+        }
     const float4* R = NLDS ? sR : A.bvh_rec;
     const uint32_t* L = NLDS ? sL : A.bvh_link;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -433,10 +456,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
         const bool walking = node != n;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
-        trace_bvh<SGN, CAP, TAIL>(R, L, n, A.geo, slot, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
+        trace_bvh<SGN, NLDS, CAP, TAIL>(R, L, n, A.geo, slot, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
         if (walking && node == n) {
 #else
-        trace_bvh<SGN, CAP, TAIL>(R, L, n, A.geo, slot, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
+        trace_bvh<SGN, NLDS, CAP, TAIL>(R, L, n, A.geo, slot, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
         if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
 #endif

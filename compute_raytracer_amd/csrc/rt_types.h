@@ -49,7 +49,7 @@ struct RtFrameArgs {
     uint32_t queue_cap;
     // bounding-sphere hierarchy of the sphere scene (rt_bvh.hip), depth-first with skip links
     const float4* bvh_rec;     // [bvh_nodes] node records, same layout as geo_f (leaves ARE geo_f records)
-    const uint32_t* bvh_link;  // [bvh_nodes] inner node: index after its subtree; leaf: 0x80000000 | sphere
+    const uint32_t* bvh_link;  // [bvh_nodes] inner node: 4 * (index after its subtree); leaf: 0x80000000 | sphere
     uint32_t bvh_nodes;        // 0: no hierarchy built
 };
 
