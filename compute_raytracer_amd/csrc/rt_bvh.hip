@@ -401,9 +401,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     __syncthreads();
 
     const Scene sc = unpack_scene(A);
+    bool flat_sky = true;
+    for (int f = 0; f < 6; ++f) flat_sky = flat_sky && A.fw[f] == 1u && A.fh[f] == 1u;
     const uint32_t tiles_x = (A.W + 7u) / 8u;
     const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
     uint32_t cur = 0, end = 0;                                   // wave-uniform chunk cursor
+    uint32_t chunk_ty = 0, chunk_tx = 0;                         // the chunk's tile (a chunk is one 8x8 tile)
     bool exhausted = false;
 
     // per-lane path state (RK:101-144 unrolled into a state machine)
@@ -427,18 +430,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 if (base >= total) { exhausted = true; break; }
                 cur = base;
                 end = min(base + 64u, total);
+                chunk_ty = (base >> 6) / tiles_x;
+                chunk_tx = (base >> 6) - chunk_ty * tiles_x;
             }
             const uint32_t take = min((uint32_t)__popcll(idle), end - cur);
             const uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (!active && r < take) {
-                const uint32_t id = cur + r, tile = id >> 6, l = id & 63u;
-                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                const uint32_t l = (cur + r) & 63u;
+                const uint32_t ty = chunk_ty, tx = chunk_tx;
                 const uint32_t x = tx * 8u + (l & 7u), row = l >> 3;
                 const uint32_t y = (A.tile_first + ty * A.tile_step) * 8u + row;
                 if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
                     opix = (ty * 8u + row) * A.W + x;
                     ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
-                    if (sc.bounces == 0u) fog = scale(sc.minIntensity, cube_sample(A, rd, lut));   // no ray will be cast
+                    if (sc.bounces == 0u) fog = scale(sc.minIntensity, cube_sample(A, rd, lut, flat_sky));   // no ray will be cast
                     color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
                     affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
                     shadow = false;
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 // One sky sample serves RK:124 (the ray missed) and RK:93-96 (the fog colour of
                 // the pixel = the sky along the PRIMARY direction, which is rd at bounce 0).
                 v3 sky = V(0, 0, 0);
-                if (bounce == 0u || idx < 0) sky = scale(sc.minIntensity, cube_sample(A, rd, lut));
+                if (bounce == 0u || idx < 0) sky = scale(sc.minIntensity, cube_sample(A, rd, lut, flat_sky));
                 if (bounce == 0u) fog = sky;
                 if (idx < 0) {                                           // RK:122-126
                     color = divs(add(scale(sum, color), scale(affect, sky)), next);

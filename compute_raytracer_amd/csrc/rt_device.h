@@ -35,7 +35,10 @@ __device__ __forceinline__ v3 texel(const uint8_t* __restrict__ f, int w, int h,
 }
 __device__ __forceinline__ v3 lerp3(v3 a, v3 b, float f) { return add(a, scale(f, sub(b, a))); }
 
-__device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = nullptr) {
+// flat: every face is a single texel (wave-uniform, the constant sky of the BASELINE configs):
+// all four taps are that texel, c, and lerp(c, c, w) = c + w * (c - c) is c for finite weights and
+// NaN otherwise -- the sample is formed as c + (wu * 0 + wv * 0), the same values with one fetch.
+__device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = nullptr, bool flat = false) {
     const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
     int face; float sc, tc, ma;
     if (az >= ax && az >= ay) {
@@ -60,6 +63,11 @@ __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = 
     const float fu = floorf(u), fv = floorf(v);
     const float wu = u - fu, wv = v - fv;
     const int x0 = (int)fu, y0 = (int)fv;
+    if (flat) {
+        const v3 c = texel(f, 1, 1, 0, 0, lut);
+        const float z = wu * 0.0f + wv * 0.0f;
+        return V(c.x + z, c.y + z, c.z + z);
+    }
     const v3 c00 = texel(f, w, h, x0, y0, lut), c10 = texel(f, w, h, x0 + 1, y0, lut);
     const v3 c01 = texel(f, w, h, x0, y0 + 1, lut), c11 = texel(f, w, h, x0 + 1, y0 + 1, lut);
     return lerp3(lerp3(c00, c10, wu), lerp3(c01, c11, wu), wv);
