@@ -26,21 +26,27 @@
 //
 // Why a node test cannot lose a hit.  Notation: unit direction h, leaf sphere (c, r) with
 // L = |o - c|, node (C, R), D = |C - c| <= Rg - r where Rg = max over members (|C - c_i| + r_i);
-// rho_x = distance of the ray's LINE from x, T = h.(C - o); u = 2^-24, kappa = 2^-16.
+// rho_x = distance of the ray's LINE from x, T = h.(C - o); u = 2^-24.  The walk scales h by
+// (1 + kappa_h), kappa_h = 2^-14 (four times the kappa of rt_filter.h: a leaf test only gets more
+// permissive, its proof stands).
 //   1. A literal hit (HK:316-318) needs disc > 0 and t > 0.001.  The rounding of the literal
-//      discriminant is below 24u (L^2 + r^2) =: d, so rho_c^2 <= r^2 + d, and t > 0.001 puts c in
-//      front of the origin (the host allows the sign-aware form only for reach < 342, where the
-//      rounding of h.oc cannot flip that).
+//      discriminant, divided by 4a, is below 20u L^2 + 6u r^2 < 24u (L^2 + r^2) =: d (oc: u per
+//      component; dot products: 4u |d||oc| and 5u |oc|^2; b*b: 36u; 4a*c: 40u; the difference: 4u,
+//      in units of |d|^2 |oc|^2), so rho_c^2 <= r^2 + d; and t > 0.001 puts c in front of the
+//      origin (the host allows the sign-aware form only for reach < 342, where the rounding of
+//      h.oc cannot flip that).
 //   2. The node test evaluates, in the filter's fused form (rt_filter.h), a value that exceeds
-//      (1+kappa)^2 T^2 - |o-C|^2 + R^2 by more than its own rounding (the eps terms), so it passes
-//      whenever rho_C^2 < R^2 + 2 kappa T^2.  The stored radius is R = Rg (1 + sigma), sigma = 0.16:
-//      near origins, L < 128 Rg:  sqrt(d) < 0.154 Rg, so rho_C <= sqrt(r^2 + d) + D < Rg (1 + sigma) = R;
-//      far origins,  L >= 128 Rg: rho_C^2 - Rg^2 <= d + 2 D sqrt(d) <= (1.43e-6 + 1.87e-5) L^2, while
-//                                 T >= 0.99 L gives 2 kappa T^2 >= 2.99e-5 L^2.
+//      (1+kappa_h)^2 T^2 - |o-C|^2 + R^2 by more than its own rounding (the eps terms), so it
+//      passes whenever rho_C^2 < R^2 + 2 kappa_h T^2.  The stored radius is R = Rg (1 + sigma),
+//      sigma = 0.04:
+//      near origins, L < 32 Rg:  sqrt(d) < 0.0383 Rg, so rho_C <= sqrt(r^2 + d) + D < Rg (1 + sigma) = R;
+//      far origins,  L >= 32 Rg: rho_C^2 - Rg^2 <= d + 2 D sqrt(d) <= (1.43e-6 + 7.48e-5) L^2, while
+//                                T >= 0.967 L gives 2 kappa_h T^2 >= 1.14e-4 L^2.
 //   3. Sign-aware form min(b,0)^2 - (|o-C|^2 - R^2) > 0: a computed b < 0 is the unsigned test.  A
 //      computed b >= 0 means T <= 7.3e-7 |o-C| while c is ahead; with P the point of closest
-//      approach to c, |o-C|^2 = |P-C|^2 - t_c^2 + 2 t_c T <= (D + sqrt(r^2+d))^2 (1 + 2e-6) < R^2:
-//      the origin is inside the node and the test passes on its second term.
+//      approach to c, |o-C|^2 = |P-C|^2 - t_c^2 + 2 t_c T <= (D + sqrt(r^2+d))^2 (1 + 2e-6), and here
+//      L <= 2.1 Rg, so sqrt(d) < 0.003 Rg and |o-C| < 1.004 Rg < R: the origin is inside the node
+//      and the test passes on its second term.
 // The argument is checked the only way that counts: frames are compared bit for bit with the
 // oracle (tests/test_bvh_gpu.py: golden frames, random scenes over five orders of magnitude).
 #include <algorithm>
@@ -158,7 +164,7 @@ struct Builder {
         const double Cd[3] = {C[0], C[1], C[2]};                       // the radius is taken about THAT point
         uint32_t unused = 0;
         double R = radius_at(Cd, unused);
-        R *= 1.16;            // sigma, see the header
+        R *= 1.04;            // sigma, see the header
         const double c2 = (double)C[0] * C[0] + (double)C[1] * C[1] + (double)C[2] * C[2];
         const double k = c2 * (1.0 - (double)RT_FILTER_EPS) - R * R * (1.0 + (double)RT_FILTER_KAPPA);
         out[0] = C[0] * RT_FILTER_SCALE; out[1] = C[1] * RT_FILTER_SCALE; out[2] = C[2] * RT_FILTER_SCALE;
@@ -235,6 +241,8 @@ uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4
 // same box): C3 3.93 / 3.51 / 3.36 / 3.40 / 3.44 ms and C5 40.7 / 32.5 / 29.1 / 27.8 / 27.3 ms for
 // 0 / 8 / 16 / 24 / 32: the larger the scene, the longer the walk relative to the shading a
 // suspension repeats.
+#define RT_BVH_KAPPA 6.103515625e-05f   /* kappa_h = 2^-14: inflation of the ray direction in the walk */
+
 #ifndef RT_BVH_TAIL_SMALL
 #define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres) */
 #endif
@@ -293,7 +301,7 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     const float a = dot(d, d);           // HK:308
     const float fa = 4.0f * a;           // the (4*a) of HK:311
     const float ta = 2.0f * a;           // HK:317
-    const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_FILTER_KAPPA);
+    const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_BVH_KAPPA);
     const v3 h = V(d.x * inv, d.y * inv, d.z * inv);
     const v3 os = V(o.x * RT_FILTER_SCALE, o.y * RT_FILTER_SCALE, o.z * RT_FILTER_SCALE);   // exact
     const v3 m = V(-2.0f * os.x, -2.0f * os.y, -2.0f * os.z);

@@ -143,3 +143,26 @@ def test_sky_shortcut_for_single_texel_faces(oracle, kind):
     img, st = gpu_render(scene, 160, 120, 5, strict=False, skybox=sky, variant=BVH)
     assert np.array_equal(img, ref), diff_stats(img, ref)
     assert st["rays"] == rays
+
+
+@pytest.mark.parametrize("dist,radius,seed", [(30.0, 0.02, 1), (300.0, 0.3, 2), (300.0, 0.05, 3), (3000.0, 2.0, 4),
+                                              (120.0, 0.01, 5), (8000.0, 8.0, 6)])
+def test_small_spheres_far_from_every_origin(oracle, dist, radius, seed):
+    """Origins 100 .. 10000 node radii away: the regime where the literal discriminant is mostly
+    rounding noise and a node test holds only through the kappa_h T^2 term of its proof."""
+    rng = np.random.default_rng(seed)
+    n = 600
+    pos = np.stack([rng.uniform(-1.0, 1.0, n) * dist, rng.uniform(-0.6, 0.6, n) * dist,
+                    -dist * rng.uniform(0.9, 1.1, n)], axis=1)
+    spheres = [rt.Sphere(p, radius * float(rng.uniform(0.5, 2.0)), rng.uniform(0.2, 1.0, 3)) for p in pos]
+    scene = rt.SceneRaytracing().createScene(spheres)
+    scene.camera.position = [0.0, 0.0, 0.0]
+    scene.camera.eulers = np.array([270.0, 90.0], np.float32)      # looking down -z
+    scene.camera.update()
+    scene.light.position = [0.1 * dist, 0.8 * dist, -0.2 * dist]
+    W, H, B = 512, 320, 4
+    ref, _, rays = oracle_render(oracle, scene, W, H, B)
+    assert rays > W * H                                             # some primary rays do hit
+    img, st = gpu_render(scene, W, H, B, strict=False, variant=BVH)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays
