@@ -6,6 +6,7 @@
 #include "rt_types.h"
 #include "rt_tri_types.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -39,18 +40,30 @@ uint32_t tiles_total(uint32_t H) { return (H + 7u) / 8u; }
 
 }  // namespace
 
+// Frames the library itself keeps concurrent (rt_render rotates over this many streams and colour
+// buffers).  Why: at the end of a frame every lane of the persistent hierarchy kernel still carries
+// a path of up to 2*bounces dependent rays; that tail is latency, not work (0.45 ms of a 2.9 ms C3
+// frame, 0.45 of 0.8 ms when 8 ranks share the frame).  Frames in flight each take a share of the
+// chip (RtFrameArgs::grid_share), so one frame's tail runs beside the others' bulk.
+constexpr int kStreams = 3;
+
 struct rt_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t last_stream = nullptr;   // stream of the last enqueued render
+    hipStream_t stream = nullptr;        // uploads, read-back, and frames 0, 3, 6 ... of rt_render (= streams[0])
+    hipStream_t streams[kStreams] = {nullptr};   // rt_render rotates: consecutive frames may overlap on the device
     hipEvent_t ev_prep0[RT355_MAX_IN_FLIGHT] = {nullptr}, ev_k0[RT355_MAX_IN_FLIGHT] = {nullptr},
-               ev_k1[RT355_MAX_IN_FLIGHT] = {nullptr};
+               ev_k1[RT355_MAX_IN_FLIGHT] = {nullptr}, ev_done[RT355_MAX_IN_FLIGHT] = {nullptr};
+    hipEvent_t ev_scene = nullptr;       // the scene arrays / hierarchy a frame reads are complete ...
+    hipStream_t scene_stream = nullptr;  // ... recorded on this stream
     uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
+    hipStream_t slot_stream[RT355_MAX_IN_FLIGHT] = {nullptr};   // the stream each of them was enqueued on
+    uint32_t frames_rendered = 0;        // rt_render calls: parity selects stream and colour buffer
     uint32_t W = 0, H = 0;
     uint32_t rank = 0, world = 1;
     float params[24] = {0};
     bool have_params = false;
-    bool scene_dirty = true;             // params or spheres changed since the last prep
+    bool prep_spheres_valid = false;     // prep_spheres ran since the last rt_write_spheres
+    bool prep_params_valid = false;      // ... and since the last rt_write_params (camera / light records)
     float* d_records = nullptr;
     uint32_t n = 0, cap_n = 0;
     bool have_spheres = false;
@@ -68,9 +81,10 @@ struct rt_ctx {
     bool bvh_valid = false;              // built for the current spheres
     uint8_t* d_face[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
-    uint8_t* d_out = nullptr;
+    uint8_t* d_out = nullptr;              // colour buffer of the LATEST rt_render (one of d_outs)
+    uint8_t* d_outs[kStreams] = {nullptr};
     size_t out_bytes = 0;
-    unsigned long long* d_rays = nullptr;  // 32-byte control block: rays (u64), queue count, queue head, tile-pair cursor
+    unsigned long long* d_rays = nullptr;  // per frame in flight a 32-byte control block: rays (u64), queue count, queue head, pixel / tile-pair cursor
     float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
     size_t queue_cap = 0;                  // entries
     unsigned long long* h_rays = nullptr;  // pinned
@@ -114,21 +128,24 @@ int rt_create(int device, rt_ctx** out) {
     if (!c) return fail(RT_ERR_HIP, "rt_create: out of host memory");
     c->device = device;
     hipError_t err;
-    err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    err = hipSuccess;
+    for (int k = 0; k < kStreams && err == hipSuccess; ++k) err = hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking);
+    c->stream = c->streams[0];
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_scene, hipEventDisableTiming);
     for (int i = 0; i < RT355_MAX_IN_FLIGHT && err == hipSuccess; ++i) {
         if ((err = hipEventCreate(&c->ev_prep0[i])) != hipSuccess) break;
         if ((err = hipEventCreate(&c->ev_k0[i])) != hipSuccess) break;
-        err = hipEventCreate(&c->ev_k1[i]);
+        if ((err = hipEventCreate(&c->ev_k1[i])) != hipSuccess) break;
+        err = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
     }
     if (err != hipSuccess ||
-        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), 32)) != hipSuccess ||
-        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), sizeof(unsigned long long), hipHostMallocDefault)) !=
-            hipSuccess) {
+        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), 32u * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
+        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), sizeof(unsigned long long) * RT355_MAX_IN_FLIGHT,
+                             hipHostMallocDefault)) != hipSuccess) {
         rt_destroy(c);
         return fail_hip(err, "rt_create: stream/event/counter setup");
     }
-    *c->h_rays = 0;
-    c->last_stream = c->stream;
+    for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) c->h_rays[i] = 0;
     *out = c;
     return RT_OK;
 }
@@ -136,12 +153,13 @@ int rt_create(int device, rt_ctx** out) {
 int rt_destroy(rt_ctx* c) {
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->last_stream && c->last_stream != c->stream && c->in_flight) (void)hipStreamSynchronize(c->last_stream);
+    for (uint32_t i = 0; i < c->in_flight; ++i) (void)hipEventSynchronize(c->ev_done[i]);
+    for (int k = 0; k < kStreams; ++k)
+        if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_scene);
     for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
-    (void)hipFree(c->d_out);
+    for (int k = 0; k < kStreams; ++k) (void)hipFree(c->d_outs[k]);
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
@@ -153,8 +171,11 @@ int rt_destroy(rt_ctx* c) {
         if (c->ev_prep0[i]) (void)hipEventDestroy(c->ev_prep0[i]);
         if (c->ev_k0[i]) (void)hipEventDestroy(c->ev_k0[i]);
         if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
     }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev_scene) (void)hipEventDestroy(c->ev_scene);
+    for (int k = 0; k < kStreams; ++k)
+        if (c->streams[k]) (void)hipStreamDestroy(c->streams[k]);
     delete c;
     return RT_OK;
 }
@@ -173,17 +194,25 @@ uint32_t rt_padded_tiles(uint32_t height, uint32_t world) {
     return (tiles_total(height) + world - 1u) / world;
 }
 
+// Scene-setup calls change device state that frames in flight may read: they drain first.
+static int drain(rt_ctx* c) { return c->in_flight ? rt_wait(c) : RT_OK; }
+
 static int ensure_out(rt_ctx* c) {
-    // sized for the padded tile count so that the buffer can be an all-gather operand
+    // sized for the padded tile count so that the buffer can be an all-gather operand; one
+    // buffer per stream rt_render rotates over (consecutive frames may overlap on the device)
     const size_t need = (size_t)rt_padded_tiles(c->H, c->world) * 8u * c->W * 4u;
-    if (need > c->out_bytes || !c->d_out) {
+    if (need > c->out_bytes || !c->d_outs[0]) {
         RT_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->d_out);
+        for (int k = 0; k < kStreams; ++k) { (void)hipFree(c->d_outs[k]); c->d_outs[k] = nullptr; }
         c->d_out = nullptr;
         c->out_bytes = 0;
         if (need) {
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_out), need));
-            RT_HIP(hipMemsetAsync(c->d_out, 0, need, c->stream));
+            for (int k = 0; k < kStreams; ++k) {
+                RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_outs[k]), need));
+                RT_HIP(hipMemsetAsync(c->d_outs[k], 0, need, c->stream));
+            }
+            RT_HIP(hipStreamSynchronize(c->stream));
+            c->d_out = c->d_outs[0];
             c->out_bytes = need;
         }
     }
@@ -205,6 +234,7 @@ int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
     if (width == 0 || height == 0 || width > 65536u || height > 65536u)
         return fail(RT_ERR_INVALID_ARG, "rt_resize: width/height must be in 1..65536");
     RT_HIP(hipSetDevice(c->device));
+    { int rc = drain(c); if (rc != RT_OK) return rc; }
     c->W = width;
     c->H = height;
     return ensure_out(c);
@@ -214,6 +244,7 @@ int rt_set_partition(rt_ctx* c, uint32_t rank, uint32_t world) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_set_partition: ctx is NULL");
     if (world == 0 || rank >= world) return fail(RT_ERR_INVALID_ARG, "rt_set_partition: need rank < world");
     RT_HIP(hipSetDevice(c->device));
+    { int rc = drain(c); if (rc != RT_OK) return rc; }
     c->rank = rank;
     c->world = world;
     if (c->W && c->H) return ensure_out(c);
@@ -224,7 +255,7 @@ int rt_write_params(rt_ctx* c, const float params[24]) {
     if (!c || !params) return fail(RT_ERR_INVALID_ARG, "rt_write_params: NULL argument");
     std::memcpy(c->params, params, sizeof c->params);   // travels in the kernarg segment
     c->have_params = true;
-    c->scene_dirty = true;
+    c->prep_params_valid = false;
     return RT_OK;
 }
 
@@ -232,6 +263,7 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
     if (!c || (n && !records)) return fail(RT_ERR_INVALID_ARG, "rt_write_spheres: NULL argument");
     if (n > (1u << 24)) return fail(RT_ERR_INVALID_ARG, "rt_write_spheres: more than 2^24 spheres");
     RT_HIP(hipSetDevice(c->device));
+    { int rc = drain(c); if (rc != RT_OK) return rc; }
     if (n > c->cap_n) {
         RT_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_records); (void)hipFree(c->d_scene);
@@ -261,7 +293,7 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
         c->scene_bound = (float)bound;
     }
     c->have_spheres = true;
-    c->scene_dirty = true;
+    c->prep_spheres_valid = false;
     return RT_OK;
 }
 
@@ -271,6 +303,7 @@ int rt_write_cubemap_face(rt_ctx* c, int face, uint32_t w, uint32_t h, const uin
     if (w == 0 || h == 0 || w > 16384u || h > 16384u)
         return fail(RT_ERR_INVALID_ARG, "rt_write_cubemap_face: face size must be in 1..16384");
     RT_HIP(hipSetDevice(c->device));
+    { int rc = drain(c); if (rc != RT_OK) return rc; }
     const size_t bytes = (size_t)w * h * 4u;
     if (c->fw[face] != w || c->fh[face] != h || !c->d_face[face]) {
         RT_HIP(hipStreamSynchronize(c->stream));
@@ -290,10 +323,10 @@ int rt_write_cubemap_face(rt_ctx* c, int face, uint32_t w, uint32_t h, const uin
 // already there), copies, and returns once the caller's memory is no longer needed
 static int write_buf(rt_ctx* c, rt_ctx::DevBuf& b, size_t byte_offset, const void* data, size_t bytes, const char* who) {
     RT_HIP(hipSetDevice(c->device));
+    { int rc = drain(c); if (rc != RT_OK) return rc; }
     const size_t need = byte_offset + bytes;
     if (need > b.cap) {
         RT_HIP(hipStreamSynchronize(c->stream));
-        if (c->last_stream != c->stream && c->in_flight) RT_HIP(hipStreamSynchronize(c->last_stream));
         void* np = nullptr;
         const size_t cap = need < 256 ? 256 : need;
         RT_HIP(hipMalloc(&np, cap));
@@ -391,9 +424,48 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     for (int i = 0; i < 6; ++i)
         if (!c->d_face[i]) return fail(RT_ERR_STATE, "rt_render: all six cube map faces must be written first");
     RT_HIP(hipSetDevice(c->device));
-    if (c->in_flight && s != c->last_stream) {   // frames in flight stay on one stream
-        int rc = rt_wait(c);
+
+    // ---- which kernels render this frame ----
+    // reach: bound on |ray origin| and on |center| + radius.  The sign-aware filter is valid only
+    // while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays below half of the 0.001 a
+    // valid hit needs (rt_filter.h: filter_one); beyond 2^20 (or NaN) the 2^40-scaled filter
+    // arithmetic could overflow, and the frame is rendered by the literal kernel instead.
+    double reach = c->scene_bound;
+    uint32_t signed_filter = 0;
+    {
+        const float* p = c->params;
+        const double cam = std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
+        const double lgt = std::sqrt((double)p[16] * p[16] + (double)p[17] * p[17] + (double)p[18] * p[18]);
+        if (!(cam <= reach)) reach = cam;
+        if (!(lgt <= reach)) reach = lgt;
+        signed_filter = (reach == reach && 2.0 * reach * 7.3e-7 < 5.0e-4) ? 1u : 0u;
+    }
+    const bool filter_ok = reach < 1048576.0;
+    // Fast mode renders through the bounding-sphere hierarchy (rt_bvh.hip) from 128 spheres on
+    // (default, variant 0; measured crossover against the brute-force kernels ~100 spheres) or
+    // whenever variant 4 asks for it; variant 5 is the brute-force default, 1-3 its forms.
+    const bool use_bvh = !tri && c->mode == RT_MODE_FAST && filter_ok && c->n > 0 &&
+                         (c->variant == 4 || (c->variant == 0 && c->n >= 128u));
+    // Frames in flight: the hierarchy kernel and the triangle kernels write nothing but their
+    // own control block and `dst`, so consecutive frames may overlap on the device (the next
+    // frame's workgroups start while the last paths of this one finish); the brute-force
+    // pipeline shares one path queue and is serialised behind the frames in flight.
+    const bool overlap_ok = tri || use_bvh;
+    const bool need_prep = !tri && c->n && (!c->prep_spheres_valid || (!use_bvh && !c->prep_params_valid));
+    const bool need_bvh = use_bvh && !c->bvh_valid;
+
+    if (need_bvh) {   // host build; the device arrays may be reallocated: nothing may be in flight
+        int rc = drain(c);
         if (rc != RT_OK) return rc;
+        const uint32_t nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link);
+        if (nodes + 1u > c->bvh_cap) {
+            (void)hipFree(c->d_bvh_rec); (void)hipFree(c->d_bvh_link);
+            c->d_bvh_rec = nullptr; c->d_bvh_link = nullptr; c->bvh_cap = 0;
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_rec), ((size_t)nodes + 1u) * sizeof(float4)));
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_link), ((size_t)nodes + 1u) * sizeof(uint32_t)));
+            c->bvh_cap = nodes + 1u;
+        }
+        c->bvh_nodes = nodes;
     }
     if (c->in_flight == RT355_MAX_IN_FLIGHT) {   // event ring full: drain
         int rc = rt_wait(c);
@@ -401,9 +473,28 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     }
     const uint32_t slot = c->in_flight;
 
+    // ---- ordering against the frames in flight and against the last scene update ----
+    if (need_prep || need_bvh || !overlap_ok) {
+        for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[i], 0));
+    }
+    if (c->scene_stream && c->scene_stream != s) RT_HIP(hipStreamWaitEvent(s, c->ev_scene, 0));
+
+    RtFrameArgs fa;
+    std::memcpy(fa.p, c->params, sizeof fa.p);
+    fa.W = c->W; fa.H = c->H; fa.N = c->n; fa.N16 = c->n16;
+    fa.tile_first = c->rank; fa.tile_step = c->world; fa.n_local_tiles = local_tiles(c);
+    fa.signed_filter = signed_filter;
+    {
+        const float4* b = c->d_scene;
+        const uint32_t m = c->n16;
+        fa.geo = b; fa.lgt = b + m; fa.cam = b + 2u * m; fa.col = b + 3u * m;
+        fa.geo_f = b + 4u * m; fa.lgt_f = b + 5u * m; fa.cam_f = b + 6u * m;
+        const float* w = reinterpret_cast<const float*>(b + 7u * m);
+        fa.geo_w = w; fa.lgt_w = w + m; fa.cam_w = w + 2u * m;
+    }
+
     RT_HIP(hipEventRecord(c->ev_prep0[slot], s));
-    if (s != c->stream) c->scene_dirty = true;   // no ordering between streams is assumed
-    if (!tri && c->scene_dirty && c->n) {
+    if (need_prep) {
         RtPrepArgs pa;
         std::memcpy(pa.p, c->params, sizeof pa.p);
         pa.N = c->n; pa.N16 = c->n16;
@@ -415,68 +506,47 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         float* w = reinterpret_cast<float*>(b + 7u * m);
         pa.geo_w = w; pa.lgt_w = w + m; pa.cam_w = w + 2u * m;
         RT_HIP(rt_launch_prep(pa, s));
+        c->prep_spheres_valid = true;
+        c->prep_params_valid = true;
     }
-    c->scene_dirty = (s != c->stream);
-    RT_HIP(hipMemsetAsync(c->d_rays, 0, 32, s));
-
-    RtFrameArgs fa;
-    std::memcpy(fa.p, c->params, sizeof fa.p);
-    fa.W = c->W; fa.H = c->H; fa.N = c->n; fa.N16 = c->n16;
-    fa.tile_first = c->rank; fa.tile_step = c->world; fa.n_local_tiles = local_tiles(c);
-    {
-        const float4* b = c->d_scene;
-        const uint32_t m = c->n16;
-        fa.geo = b; fa.lgt = b + m; fa.cam = b + 2u * m; fa.col = b + 3u * m;
-        fa.geo_f = b + 4u * m; fa.lgt_f = b + 5u * m; fa.cam_f = b + 6u * m;
-        const float* w = reinterpret_cast<const float*>(b + 7u * m);
-        fa.geo_w = w; fa.lgt_w = w + m; fa.cam_w = w + 2u * m;
+    if (need_bvh) {
+        const size_t nn = (size_t)c->bvh_nodes + 1u;
+        RT_HIP(hipMemcpyAsync(c->d_bvh_rec, c->h_bvh_rec.data(), nn * sizeof(float4), hipMemcpyHostToDevice, s));
+        RT_HIP(hipMemcpyAsync(c->d_bvh_link, c->h_bvh_link.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        RT_HIP(hipStreamSynchronize(s));   // pageable sources: the vectors may be rebuilt later
+        RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, fa.geo_f, s));
+        c->bvh_valid = true;
     }
-    // reach: bound on |ray origin| and on |center| + radius.  The sign-aware filter is valid only
-    // while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays below half of the 0.001 a
-    // valid hit needs (rt_filter.h: filter_one); beyond 2^20 (or NaN) the 2^40-scaled filter
-    // arithmetic could overflow, and the frame is rendered by the literal kernel instead.
-    double reach = c->scene_bound;
-    {
-        const float* p = c->params;
-        const double cam = std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
-        const double lgt = std::sqrt((double)p[16] * p[16] + (double)p[17] * p[17] + (double)p[18] * p[18]);
-        if (!(cam <= reach)) reach = cam;
-        if (!(lgt <= reach)) reach = lgt;
-        fa.signed_filter = (reach == reach && 2.0 * reach * 7.3e-7 < 5.0e-4) ? 1u : 0u;
+    if (need_prep || need_bvh) {
+        RT_HIP(hipEventRecord(c->ev_scene, s));
+        c->scene_stream = s;
     }
-    const bool filter_ok = reach < 1048576.0;
-    // Fast mode renders through the bounding-sphere hierarchy (rt_bvh.hip) from 128 spheres on
-    // (default, variant 0; measured crossover against the brute-force kernels ~100 spheres) or
-    // whenever variant 4 asks for it; variant 5 is the brute-force default, 1-3 its forms.  The
-    // hierarchy is (re)built on the host when the spheres changed.
-    const bool use_bvh = !tri && c->mode == RT_MODE_FAST && filter_ok && c->n > 0 &&
-                         (c->variant == 4 || (c->variant == 0 && c->n >= 128u));
-    fa.bvh_rec = nullptr; fa.bvh_link = nullptr; fa.bvh_nodes = 0;
-    if (use_bvh) {
-        if (!c->bvh_valid) {
-            const uint32_t nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link);
-            if (nodes + 1u > c->bvh_cap) {
-                RT_HIP(hipStreamSynchronize(s));
-                (void)hipFree(c->d_bvh_rec); (void)hipFree(c->d_bvh_link);
-                c->d_bvh_rec = nullptr; c->d_bvh_link = nullptr; c->bvh_cap = 0;
-                RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_rec), ((size_t)nodes + 1u) * sizeof(float4)));
-                RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_link), ((size_t)nodes + 1u) * sizeof(uint32_t)));
-                c->bvh_cap = nodes + 1u;
-            }
-            RT_HIP(hipMemcpyAsync(c->d_bvh_rec, c->h_bvh_rec.data(), ((size_t)nodes + 1u) * sizeof(float4), hipMemcpyHostToDevice, s));
-            RT_HIP(hipMemcpyAsync(c->d_bvh_link, c->h_bvh_link.data(), ((size_t)nodes + 1u) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            RT_HIP(hipStreamSynchronize(s));   // pageable sources: the vectors may be rebuilt next frame
-            RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, nodes, fa.geo_f, s));
-            c->bvh_nodes = nodes;
-            c->bvh_valid = true;
+    fa.bvh_rec = use_bvh ? c->d_bvh_rec : nullptr;
+    fa.bvh_link = use_bvh ? c->d_bvh_link : nullptr;
+    fa.bvh_nodes = use_bvh ? c->bvh_nodes : 0u;
+    // frames in flight on DIFFERENT streams run concurrently and share the chip: this frame's grid is
+    // 1 / (number of distinct streams among it and the kStreams-1 frames enqueued before it)
+    c->slot_stream[slot] = s;
+    fa.grid_share = 1u;
+    if (overlap_ok) {
+        hipStream_t seen[kStreams] = {s};
+        uint32_t distinct = 1;
+        for (uint32_t back = 1; back < (uint32_t)kStreams && back <= slot; ++back) {
+            hipStream_t o = c->slot_stream[slot - back];
+            bool known = false;
+            for (uint32_t j = 0; j < distinct; ++j) known = known || seen[j] == o;
+            if (!known) seen[distinct++] = o;
         }
-        fa.bvh_rec = c->d_bvh_rec; fa.bvh_link = c->d_bvh_link; fa.bvh_nodes = c->bvh_nodes;
+        fa.grid_share = distinct;
     }
+
+    unsigned long long* ctrl = c->d_rays + 4u * slot;          // this frame's 32-byte control block
+    RT_HIP(hipMemsetAsync(ctrl, 0, 32, s));
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
     fa.out = dst;
-    fa.rays = c->d_rays;
+    fa.rays = ctrl;
     fa.queue = c->d_queue;
-    fa.qctrl = reinterpret_cast<uint32_t*>(c->d_rays) + 2;
+    fa.qctrl = reinterpret_cast<uint32_t*>(ctrl) + 2;
     fa.queue_cap = (uint32_t)c->queue_cap;
     RtLaunchCfg cfg;
     cfg.mode = filter_ok ? c->mode : (int)RT_MODE_STRICT;
@@ -503,15 +573,21 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
-    RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    c->last_stream = s;
+    RT_HIP(hipMemcpyAsync(c->h_rays + slot, ctrl, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    RT_HIP(hipEventRecord(c->ev_done[slot], s));
     c->in_flight = slot + 1;
     return RT_OK;
 }
 
 int rt_render(rt_ctx* c) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_render: ctx is NULL");
-    return enqueue(c, c->d_out, c->stream);
+    // consecutive frames rotate over kStreams streams and colour buffers, so that frames enqueued
+    // back to back overlap on the device; rt_read_pixels returns the latest one
+    const uint32_t k = c->frames_rendered % (uint32_t)kStreams;
+    uint8_t* dst = c->d_outs[k];
+    int rc = enqueue(c, dst, c->streams[k]);
+    if (rc == RT_OK) { c->d_out = dst; ++c->frames_rendered; }
+    return rc;
 }
 
 int rt_render_to(rt_ctx* c, void* device_dst, size_t cap, void* hip_stream) {
@@ -525,10 +601,10 @@ int rt_render_to(rt_ctx* c, void* device_dst, size_t cap, void* hip_stream) {
 int rt_wait(rt_ctx* c) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_wait: ctx is NULL");
     RT_HIP(hipSetDevice(c->device));
-    RT_HIP(hipStreamSynchronize(c->last_stream));
+    for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipEventSynchronize(c->ev_done[i]));
     if (c->in_flight) {
         c->stats.frames += c->in_flight;
-        c->stats.rays = *c->h_rays;
+        c->stats.rays = c->h_rays[c->in_flight - 1u];
         c->stats.batch_frames = c->in_flight;
         c->stats.batch_kernel_ms = 0.0f;
         for (uint32_t i = 0; i < c->in_flight; ++i) {

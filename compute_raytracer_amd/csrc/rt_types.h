@@ -51,6 +51,7 @@ struct RtFrameArgs {
     const float4* bvh_rec;     // [bvh_nodes] node records, same layout as geo_f (leaves ARE geo_f records)
     const uint32_t* bvh_link;  // [bvh_nodes] inner node: 4 * (index after its subtree); leaf: 0x80000000 | sphere
     uint32_t bvh_nodes;        // 0: no hierarchy built
+    uint32_t grid_share;       // >1: this frame's persistent grid takes 1/grid_share of the chip (frames in flight)
 };
 
 struct RtPrepArgs {

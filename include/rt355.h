@@ -149,10 +149,17 @@ uint32_t rt_padded_tiles(uint32_t height, uint32_t world);
 
 /* Replaces beginComputePass/setPipeline/setBindGroup/dispatchWorkgroups(ceil(W/8),
  * ceil(H/8),1)/submit (RR:442-446, RR:465): enqueues scene preparation + the ray-trace
- * kernel on the context's stream and returns without waiting.  The reference keeps one
- * frame in flight (RR:467); this library allows up to RT355_MAX_IN_FLIGHT enqueued frames
- * (all on one stream, so they execute in order) and drains by itself beyond that. */
-#define RT355_MAX_IN_FLIGHT 32
+ * kernel and returns without waiting.  The reference keeps one frame in flight (RR:467) --
+ * rt_render + rt_wait per frame does the same.  A caller that enqueues frames back to back
+ * gets up to three of them running concurrently (the library rotates over three streams
+ * and three colour buffers, each concurrent frame taking a share of the chip): the
+ * dependent-ray tail of one frame then runs beside the bulk of the next.  Every frame uses
+ * the parameters and scene written before its rt_render call; rt_read_pixels returns the
+ * frame of the latest rt_render.  Up to RT355_MAX_IN_FLIGHT frames may be enqueued between
+ * two rt_wait; beyond that the library drains by itself.  Scene-setup calls (rt_write_spheres,
+ * rt_write_cubemap_face, rt_write_triangles ..., rt_resize, rt_set_partition) wait for the
+ * frames in flight first; rt_write_params does not need to. */
+#define RT355_MAX_IN_FLIGHT 64
 int rt_render(rt_ctx* ctx);
 
 /* Replaces `await queue.onSubmittedWorkDone()` (RR:467). */
@@ -168,7 +175,9 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
 
 /* As rt_render, but the kernel runs on `hip_stream` (a hipStream_t; NULL = the context's
  * stream) and writes the compact tile buffer to `device_dst` (device memory of this
- * context's GPU, >= rt_padded_tiles*8*W*4 bytes).  Nothing is copied to the host. */
+ * context's GPU, >= rt_padded_tiles*8*W*4 bytes).  Nothing is copied to the host.  Frames
+ * enqueued on different streams (into different buffers) may run concurrently, as with
+ * rt_render; frames on one stream execute in order. */
 int rt_render_to(rt_ctx* ctx, void* device_dst, size_t cap, void* hip_stream);
 
 /* De-interleaves an all-gathered buffer [world][padded_tiles][8][W][4] into the row-major
