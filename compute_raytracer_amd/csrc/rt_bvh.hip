@@ -237,12 +237,12 @@ uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4
     return nodes;
 }
 
+#define RT_BVH_KAPPA 6.103515625e-05f   /* kappa_h = 2^-14: inflation of the ray direction in the walk */
+
 // Lanes still walking below which a wave suspends the walk (0: never).  Measured (tools/ab.py,
 // same box): C3 3.93 / 3.51 / 3.36 / 3.40 / 3.44 ms and C5 40.7 / 32.5 / 29.1 / 27.8 / 27.3 ms for
 // 0 / 8 / 16 / 24 / 32: the larger the scene, the longer the walk relative to the shading a
 // suspension repeats.
-#define RT_BVH_KAPPA 6.103515625e-05f   /* kappa_h = 2^-14: inflation of the ray direction in the walk */
-
 #ifndef RT_BVH_TAIL_SMALL
 #define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres) */
 #endif
