@@ -51,3 +51,23 @@ def test_smoke_entry_point():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_bench_distributed_path_pipelines_hierarchy_frames():
+    """C3 through the N>1 code path with one rank: 7 frames rotate over the three streams and buffer
+    sets (render_to -> all-gather -> assemble), the assembled frame is the golden one."""
+    fr = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["C3"]
+    d, err = run_bench("--steps", "6", "--warmup", "1", "--config", "C3", "--no-cpu-baseline", "--force-dist",
+                       env={"RT355_BENCH_CHECK_FRAME": "1", "MASTER_PORT": "29542"})
+    sha = [l.split()[1] for l in err.splitlines() if l.startswith("frame_sha256")]
+    assert sha and sha[0] == fr["sha256"]
+    assert d["config"]["rays_per_frame"] == fr["rays"]
+    assert d["roofline"]["launches_in_flight"] == 3 and "bvh_pixels" in d["roofline"]["kernel"]
+
+
+def test_bench_serial_mode_times_single_launches():
+    d, _ = run_bench("--steps", "4", "--warmup", "1", "--config", "C3", "--no-cpu-baseline", "--serial")
+    r = d["roofline"]
+    assert r["launches_in_flight"] == 1
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["kernel_ms_avg"] <= d["ms_per_step"] * 1.05          # a launch is the bulk of a serial step
