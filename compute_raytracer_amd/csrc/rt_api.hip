@@ -1,5 +1,5 @@
 // rt_api.hip -- host side of librt355.so: the C ABI declared in include/rt355.h.
-// One context = one GPU + one stream; see the header for what each entry point replaces in
+// One context = one GPU + three streams (frames in flight); see the header for what each entry point replaces in
 // the reference's renderer-raytracing.ts.  No CPU fallback: without a gfx950 device
 // rt_create fails and nothing else can be called.
 #include "../../include/rt355.h"

@@ -79,7 +79,7 @@ typedef struct rt_stats {
 /* ---- lifetime ---------------------------------------------------------------------- */
 
 /* Replaces navigator.gpu.requestAdapter()/requestDevice() (RR:82-86).  `device` is the HIP
- * ordinal; one stream is created on it.  Fails (RT_ERR_NO_DEVICE) when no GPU is present. */
+ * ordinal; its streams are created on it.  Fails (RT_ERR_NO_DEVICE) when no GPU is present. */
 int rt_create(int device, rt_ctx** out);
 int rt_destroy(rt_ctx* ctx);
 
