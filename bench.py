@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--serial", action="store_true",
                     help="one frame at a time (render + wait, as the reference does, RR:467); default: frames are "
-                         "enqueued back to back and up to three overlap on the device")
+                         "enqueued back to back and up to four overlap on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--force-dist", action="store_true",
@@ -127,11 +127,11 @@ def main():
     r.set_variant(a.variant)
     r.recalculateScene()   # uploads: scene resident in HBM before anything is timed
 
-    FLIGHT = 3                          # frames kept concurrent (the library rotates rt_render over 3 streams itself)
+    FLIGHT = 4                          # frames kept concurrent (the library rotates rt_render over 4 streams itself)
     if multi:
         msg = tiles.message_bytes(W, H, world)
-        # frame k runs on stream k % 3: render of this rank's tiles, all-gather (RCCL's stream, ordered
-        # after the render), de-interleave; three frames are in flight, each with its own buffers
+        # frame k runs on stream k % 4: render of this rank's tiles, all-gather (RCCL's stream, ordered
+        # after the render), de-interleave; four frames are in flight, each with its own buffers
         streams = [torch.cuda.Stream() for _ in range(FLIGHT)]
         local = [torch.zeros(msg, dtype=torch.uint8, device="cuda") for _ in range(FLIGHT)]
         gathered = [torch.empty(world * msg, dtype=torch.uint8, device="cuda") for _ in range(FLIGHT)]
@@ -241,8 +241,8 @@ def main():
         roof_note = ("achieved = 25 flop x N spheres x rays per launch / time: the ALGORITHMIC work of the "
                      "reference's test-every-sphere loop (SURVEY.md 8(d)); time = the launch duration (kernel_ms_avg, "
                      "HIP events) when frames run one at a time (--serial), the frame period when launches of "
-                     "consecutive frames overlap (launches_in_flight = 3, each on a third of the chip: kernel_ms_avg is "
-                     "then ~3 frame periods)."
+                     "consecutive frames overlap (launches_in_flight = 4, each on a quarter of the chip: kernel_ms_avg is "
+                     "then ~4 frame periods)."
                      + (" The hierarchy evaluates ~5 % of those tests, so frac > 1 means 'faster than brute force could "
                         "run at the FP32 roof'; the executed-instruction view is in `executed`." if hierarchy else ""))
         executed = None

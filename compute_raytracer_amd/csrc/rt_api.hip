@@ -1,5 +1,5 @@
 // rt_api.hip -- host side of librt355.so: the C ABI declared in include/rt355.h.
-// One context = one GPU + three streams (frames in flight); see the header for what each entry point replaces in
+// One context = one GPU + four streams (frames in flight); see the header for what each entry point replaces in
 // the reference's renderer-raytracing.ts.  No CPU fallback: without a gfx950 device
 // rt_create fails and nothing else can be called.
 #include "../../include/rt355.h"
@@ -45,7 +45,7 @@ uint32_t tiles_total(uint32_t H) { return (H + 7u) / 8u; }
 // a path of up to 2*bounces dependent rays; that tail is latency, not work (0.45 ms of a 2.9 ms C3
 // frame, 0.45 of 0.8 ms when 8 ranks share the frame).  Frames in flight each take a share of the
 // chip (RtFrameArgs::grid_share), so one frame's tail runs beside the others' bulk.
-constexpr int kStreams = 3;
+constexpr int kStreams = 4;
 
 struct rt_ctx {
     int device = 0;

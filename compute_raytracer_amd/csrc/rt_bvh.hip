@@ -532,7 +532,7 @@ hipError_t launch_bvh_as(const RtFrameArgs& a, size_t lds, hipStream_t s) {
     const uint32_t per_cu = (uint32_t)std::min((size_t)(WAVES == 8 ? 3 : 1), cap / std::max(lds, (size_t)1));
     const uint32_t pixels = a.n_local_tiles * ((a.W + 7u) / 8u) * 64u;
     uint32_t blocks = 256u * (per_cu ? per_cu : 1u);
-    if (a.grid_share > 1u) blocks = std::max(256u, blocks / a.grid_share);   // frames in flight share the chip
+    if (a.grid_share > 1u) blocks = std::max(192u, blocks / a.grid_share);   // frames in flight share the chip
     const uint32_t need = (pixels + 64u * WAVES - 1u) / (64u * WAVES);
     if (blocks > need) blocks = need;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);

@@ -151,8 +151,8 @@ uint32_t rt_padded_tiles(uint32_t height, uint32_t world);
  * ceil(H/8),1)/submit (RR:442-446, RR:465): enqueues scene preparation + the ray-trace
  * kernel and returns without waiting.  The reference keeps one frame in flight (RR:467) --
  * rt_render + rt_wait per frame does the same.  A caller that enqueues frames back to back
- * gets up to three of them running concurrently (the library rotates over three streams
- * and three colour buffers, each concurrent frame taking a share of the chip): the
+ * gets up to four of them running concurrently (the library rotates over four streams
+ * and four colour buffers, each concurrent frame taking a share of the chip): the
  * dependent-ray tail of one frame then runs beside the bulk of the next.  Every frame uses
  * the parameters and scene written before its rt_render call; rt_read_pixels returns the
  * frame of the latest rt_render.  Up to RT355_MAX_IN_FLIGHT frames may be enqueued between

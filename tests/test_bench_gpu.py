@@ -54,7 +54,7 @@ def test_smoke_entry_point():
 
 
 def test_bench_distributed_path_pipelines_hierarchy_frames():
-    """C3 through the N>1 code path with one rank: 7 frames rotate over the three streams and buffer
+    """C3 through the N>1 code path with one rank: 7 frames rotate over the four streams and buffer
     sets (render_to -> all-gather -> assemble), the assembled frame is the golden one."""
     fr = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["C3"]
     d, err = run_bench("--steps", "6", "--warmup", "1", "--config", "C3", "--no-cpu-baseline", "--force-dist",
@@ -62,7 +62,7 @@ def test_bench_distributed_path_pipelines_hierarchy_frames():
     sha = [l.split()[1] for l in err.splitlines() if l.startswith("frame_sha256")]
     assert sha and sha[0] == fr["sha256"]
     assert d["config"]["rays_per_frame"] == fr["rays"]
-    assert d["roofline"]["launches_in_flight"] == 3 and "bvh_pixels" in d["roofline"]["kernel"]
+    assert d["roofline"]["launches_in_flight"] == 4 and "bvh_pixels" in d["roofline"]["kernel"]
 
 
 def test_bench_serial_mode_times_single_launches():

@@ -175,28 +175,28 @@ def test_frames_in_flight_with_a_moving_camera(oracle):
     scene = rt.SceneRaytracing().createScene(synthetic_spheres(300, 17))
     W, H, B = 256, 160, 5
     r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize()
-    streams = [torch.cuda.Stream() for _ in range(3)]
-    bufs = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(7)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    bufs = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(9)]
     torch.cuda.synchronize()
     refs = []
-    for f in range(7):
+    for f in range(9):
         scene.camera.position = [0.06 + 0.4 * f, 2.7 + 0.1 * f, 3.3 - 0.3 * f]
         scene.camera.update()
         scene.light.position = [0.5 * f, 5.0, -0.5 * f]
         refs.append(oracle_render(oracle, scene, W, H, B))
-        r.render_to(bufs[f].data_ptr(), bufs[f].numel(), streams[f % 3].cuda_stream)
+        r.render_to(bufs[f].data_ptr(), bufs[f].numel(), streams[f % 4].cuda_stream)
     r.wait()
     torch.cuda.synchronize()
-    for f in range(7):
+    for f in range(9):
         img = bufs[f].cpu().numpy().reshape(H, W, 4)
         assert np.array_equal(img, refs[f][0]), (f, diff_stats(img, refs[f][0]))
-    assert r.stats()["rays"] == refs[6][2]
-    # the plain API: seven rt_render without a wait, the read-back is the last frame
-    for f in range(7):
+    assert r.stats()["rays"] == refs[8][2]
+    # the plain API: nine rt_render without a wait, the read-back is the last frame
+    for f in range(9):
         scene.camera.position = [0.06 + 0.4 * f, 2.7 + 0.1 * f, 3.3 - 0.3 * f]
         scene.camera.update()
         scene.light.position = [0.5 * f, 5.0, -0.5 * f]
         r.recalculateScene()
         r.enqueue()
-    assert np.array_equal(r.read_pixels(), refs[6][0])
+    assert np.array_equal(r.read_pixels(), refs[8][0])
     r.close()
