@@ -664,6 +664,20 @@ int rt_assemble_frame(rt_ctx* c, const void* gathered, void* frame, uint32_t wor
     return RT_OK;
 }
 
+int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* link, uint32_t cap_nodes,
+                       uint32_t* n_nodes) {
+    if ((n && !records) || !n_nodes) return fail(RT_ERR_INVALID_ARG, "rt_build_hierarchy: NULL argument");
+    std::vector<float> r;
+    std::vector<uint32_t> l;
+    const uint32_t nodes = rt_bvh_build(records, n, r, l);
+    *n_nodes = nodes;
+    if (l.empty()) return RT_OK;                       // n == 0: nothing to write
+    if (cap_nodes < nodes + 1u || !rec4 || !link) return fail(RT_ERR_CAPACITY, "rt_build_hierarchy: need n_nodes + 1 entries");
+    std::memcpy(rec4, r.data(), r.size() * sizeof(float));
+    std::memcpy(link, l.data(), l.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
 int rt_device_pixels(rt_ctx* c, void** out_ptr, size_t* out_bytes) {
     if (!c || !out_ptr || !out_bytes) return fail(RT_ERR_INVALID_ARG, "rt_device_pixels: NULL argument");
     if (!c->d_out) return fail(RT_ERR_STATE, "rt_device_pixels: no colour buffer (rt_resize first)");

@@ -185,8 +185,21 @@ int rt_render_to(rt_ctx* ctx, void* device_dst, size_t cap, void* hip_stream);
 int rt_assemble_frame(rt_ctx* ctx, const void* gathered, void* frame, uint32_t world,
                       void* hip_stream);
 
-/* Device address of the context's own colour buffer (valid until rt_resize/rt_destroy). */
+/* Device address of the colour buffer of the latest rt_render (valid until the next
+ * rt_render / rt_resize / rt_destroy). */
 int rt_device_pixels(rt_ctx* ctx, void** out_ptr, size_t* out_bytes);
+
+/* ---- diagnostics -------------------------------------------------------------------------- */
+
+/* Runs the HOST side of the sphere path on its own -- the build of the bounding-sphere
+ * hierarchy the fast mode walks -- without a device or a context, so that it can
+ * be checked on a machine without a GPU.  `records` as for rt_write_spheres.  Writes n_nodes + 1
+ * node records (4 floats each: centre * 2^40, (|C|^2 (1-2^-17) - R^2 (1+2^-16)) * 2^80; leaf records
+ * are zero here, the device fills them) and links (inner node: 4 * index of the first node after
+ * its subtree; leaf: 0x80000000 | sphere index; the last entry is the sentinel).  RT_ERR_CAPACITY
+ * when cap_nodes < n_nodes + 1 (*n_nodes is set either way; at most 2 n + 64 nodes). */
+int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* link, uint32_t cap_nodes,
+                       uint32_t* n_nodes);
 
 #ifdef __cplusplus
 }
