@@ -77,6 +77,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RtError(RT_ERR_NO_DEVICE, "librt355.so is not built (%s); run `make lib`. There is no CPU path." % LIB_PATH)
+    # frames in flight run on four streams; HIP's default of 4 hardware queues makes streams share a
+    # queue as soon as the host has a few of its own (effective only if HIP is not initialised yet)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     _one_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t
