@@ -243,6 +243,9 @@ uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4
 // same box): C3 3.93 / 3.51 / 3.36 / 3.40 / 3.44 ms and C5 40.7 / 32.5 / 29.1 / 27.8 / 27.3 ms for
 // 0 / 8 / 16 / 24 / 32: the larger the scene, the longer the walk relative to the shading a
 // suspension repeats.
+#ifndef RT_BVH_GRAB
+#define RT_BVH_GRAB 256u   /* pixel slots per cursor atomic: a multiple of 64 (whole tiles) */
+#endif
 #ifndef RT_BVH_TAIL_SMALL
 #define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres) */
 #endif
@@ -414,7 +417,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     const uint32_t tiles_x = (A.W + 7u) / 8u;
     const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
     uint32_t cur = 0, end = 0;                                   // wave-uniform chunk cursor
-    uint32_t chunk_ty = 0, chunk_tx = 0;                         // the chunk's tile (a chunk is one 8x8 tile)
+    uint32_t chunk_ty = 0, chunk_tx = 0, chunk_first = ~0u;      // the tile the cursor is in
+    // Pixel slots a wave reserves per atomic on the frame's cursor.  One 8x8 tile per atomic made the
+    // cursor -- 130,000 returning atomics on ONE address per 4K frame, ~13 ns each -- a 1.7 ms floor
+    // under the frame time (a 1-bounce frame took as long as a 2-bounce one: 1.62 ms; now 0.74 ms).
+    constexpr uint32_t kGrab = RT_BVH_GRAB;
+    const uint32_t plenty = gridDim.x * (uint32_t)WAVES * 64u * 16u;  // sixteen tiles per resident wave
+    uint32_t grab = 64u, trips = 0u;                                  // wave-uniform
     bool exhausted = false;
 
     // per-lane path state (RK:101-144 unrolled into a state machine)
@@ -428,20 +437,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     int idx = -1;
 
     for (;;) {
+        ++trips;
         // ---- idle lanes take the next pixels ----
         uint64_t idle = __ballot(!active);
         while (idle && !exhausted) {
             if (cur == end) {
+                // One atomic reserves whole 8x8 tiles.  A wave that used up its last reservation within
+                // two trips of the outer loop (cheap pixels: few bounces, sky) doubles the next one, up to
+                // kGrab slots, while plenty of the frame is left; one that took more than eight trips goes
+                // back to one tile: expensive pixels keep the finest grain, which balances the end of the frame.
+                if (trips <= 2u && total - min(end, total) > plenty) grab = min(grab * 2u, kGrab);
+                else if (trips > 8u) grab = 64u;
+                trips = 0u;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&A.qctrl[2], 64u);
+                if (lane == 0) base = atomicAdd(&A.qctrl[2], grab);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= total) { exhausted = true; break; }
                 cur = base;
-                end = min(base + 64u, total);
-                chunk_ty = (base >> 6) / tiles_x;
-                chunk_tx = (base >> 6) - chunk_ty * tiles_x;
+                end = min(base + grab, total);
             }
-            const uint32_t take = min((uint32_t)__popcll(idle), end - cur);
+            if ((cur & 63u) == 0u || cur == chunk_first) {       // entering a tile: decode it (wave-uniform)
+                chunk_first = cur;
+                chunk_ty = (cur >> 6) / tiles_x;
+                chunk_tx = (cur >> 6) - chunk_ty * tiles_x;
+            }
+            const uint32_t tile_end = min(end, (cur & ~63u) + 64u);
+            const uint32_t take = min((uint32_t)__popcll(idle), tile_end - cur);
             const uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (!active && r < take) {
                 const uint32_t l = (cur + r) & 63u;
