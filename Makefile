@@ -24,8 +24,8 @@ $(CSRC)/rt_triangles.o: $(CSRC)/rt_triangles.hip $(CSRC)/rt_device.h $(CSRC)/rt_
 $(CSRC)/rt_assemble.o: $(CSRC)/rt_assemble.hip $(CSRC)/rt_types.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/rt_api.o: $(CSRC)/rt_api.hip $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h include/rt355.h
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/rt_api.o: $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h include/rt355.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
 
 $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)

@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4, std::vector<uint32_t>& link);   // rt_bvh.hip
+#include "rt_bvh_build.h"
 
 namespace {
 
