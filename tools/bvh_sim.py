@@ -80,6 +80,43 @@ def split_sah_diag(ids, bound):
     return best[1], best[2]
 
 
+def build_collapsed(split, bound, arity=4):
+    """binary tree by `split` down to single spheres, collapsed to `arity` by opening the child with the
+    largest radius first; same threaded layout as build()"""
+    def bin_tree(ids):
+        if len(ids) == 1: return ("l", ids[0])
+        a, b = split(ids, bound)
+        return ("n", bin_tree(a), bin_tree(b), ids)
+    rec = []; link = []
+    def leaf(i):
+        rec.append((C[i], R[i])); link.append(("l", i))
+    def kids(node):
+        ch = [node[1], node[2]]
+        while len(ch) < arity:
+            best = -1; br = -1.0
+            for k, c in enumerate(ch):
+                if c[0] == "n":
+                    r = bound(c[3])[1]
+                    if r > br: br = r; best = k
+            if best < 0: break
+            c = ch.pop(best); ch[best:best] = [c[1], c[2]]
+        return ch
+    def emit(node):
+        if node[0] == "l": leaf(node[1]); return
+        me = len(rec); rec.append(None); link.append(None)
+        for c in kids(node): emit(c)
+        bc, br = bound(node[3])
+        rec[me] = (bc, br * SIGMA); link[me] = ("n", len(rec))
+    med = np.median(R); ext = np.linalg.norm(C.max(0) - C.min(0))
+    rest = []
+    for i in range(N):
+        if N > 8 and R[i] > 8 * med and R[i] > 0.125 * ext: leaf(i)
+        else: rest.append(i)
+    root = bin_tree(np.array(rest))
+    for c in kids(root): emit(c)
+    return rec, link
+
+
 def build(split, bound, leafmax=4, arity=4):
     rec = []; link = []
     def leaf(i):
@@ -184,9 +221,13 @@ for (name, split, bound, leafmax, arity), tc in itertools.product([
         ("sahdiag/box  4/4", split_sah_diag, bound_box, 4, 4),
         ("sahdiag/ritt 4/4", split_sah_diag, bound_ritter, 4, 4),
         ("sahdiag/box  3/3", split_sah_diag, bound_box, 3, 3),
-        ("sahdiag/box  6/4", split_sah_diag, bound_box, 6, 4)][5:6], [False]):
+        ("sahdiag/box  6/4", split_sah_diag, bound_box, 6, 4),
+        ("collapse4 sahdiag", split_sah_diag, bound_ritter, 0, 4),
+        ("collapse3 sahdiag", split_sah_diag, bound_ritter, 0, 3),
+        ("collapse6 sahdiag", split_sah_diag, bound_ritter, 0, 6),
+        ("collapse2 sahdiag", split_sah_diag, bound_ritter, 0, 2)][5:], [False]):
     TCULL = tc
-    rec, link = build(split, bound, leafmax, arity)
+    rec, link = build(split, bound, leafmax, arity) if leafmax else build_collapsed(split, bound, arity)
     tests = np.array([traverse(rec, link, o, d)[2] for (_, o, d) in rays])
     cands = np.array([traverse(rec, link, o, d)[3] for (_, o, d) in rays[::7]])
     # waves: consecutive groups of 64 rays (what regeneration approximates)
