@@ -41,6 +41,32 @@ __device__ __forceinline__ NodeR load_node(const RtTriScene& T, uint32_t i) {
     return n;
 }
 
+// The head of the node buffer (the TLAS: RR:184-192 writes it at offset 0) and the BLAS records are
+// staged in LDS by every workgroup: the TLAS walk and the per-instance set-up (matrix, root index)
+// are a chain of dependent loads that every ray of every pixel pays, sky pixels included.
+constexpr uint32_t kLdsNodes = 64u, kLdsBlas = 16u;
+struct TriLds { const float4* nodes; uint32_t n_nodes; const float* blas; uint32_t n_blas; };
+__device__ __forceinline__ NodeR load_node_head(const RtTriScene& T, const TriLds& L, uint32_t i) {
+    if (i >= T.n_nodes) i = T.n_nodes - 1u;
+    if (i >= L.n_nodes) return load_node(T, i);
+    const float4 a = L.nodes[2u * i], b = L.nodes[2u * i + 1u];
+    NodeR n;
+    n.lo = V(a.x, a.y, a.z); n.left = a.w;
+    n.hi = V(b.x, b.y, b.z); n.count = b.w;
+    return n;
+}
+template <int WAVES>
+__device__ __forceinline__ TriLds stage_head(const RtTriScene& T, float4* s_nodes, float* s_blas) {
+    TriLds L;
+    L.n_nodes = T.n_nodes < kLdsNodes ? T.n_nodes : kLdsNodes;
+    L.n_blas = T.n_blas < kLdsBlas ? T.n_blas : kLdsBlas;
+    for (uint32_t i = threadIdx.x; i < 2u * L.n_nodes; i += 64 * WAVES) s_nodes[i] = T.nodes[i];
+    for (uint32_t i = threadIdx.x; i < 20u * L.n_blas; i += 64 * WAVES) s_blas[i] = T.blas[i];
+    __syncthreads();
+    L.nodes = s_nodes; L.blas = s_blas;
+    return L;
+}
+
 // RK:395-410
 __device__ __forceinline__ float hit_aabb(v3 o, v3 inv, const NodeR& n) {
     const v3 t1 = V((n.lo.x - o.x) * inv.x, (n.lo.y - o.y) * inv.y, (n.lo.z - o.z) * inv.z);   // RK:397
@@ -90,9 +116,17 @@ __device__ __forceinline__ bool hit_triangle(const RtTriScene& T, uint32_t ti, v
 
 // RK:246-332 traceBLAS (the normal transform RK:334-338 is deferred to finish_hit)
 template <bool COUNT>
-__device__ __forceinline__ void trace_blas(const RtTriScene& T, uint32_t bi, v3 o, v3 d, float& nearest,
+__device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L, uint32_t bi, v3 o, v3 d, float& nearest,
                                            TriHit& hit, uint32_t* stack, uint32_t stride, float& traces) {
-    const float* m = T.blas + 20u * (size_t)bi;                     // mat4 column-major, m[4c + r]
+    float m[17];                                                    // mat4 column-major, m[4c + r]; m[16] root index
+    if (bi < L.n_blas) {
+#pragma unroll
+        for (int k = 0; k < 17; ++k) m[k] = L.blas[20u * bi + (uint32_t)k];
+    } else {
+        const float* g = T.blas + 20u * (size_t)bi;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) m[k] = g[k];
+    }
     const v3 oo = V(((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.0f,
                     ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.0f,
                     ((m[2] * o.x + m[6] * o.y) + m[10] * o.z) + m[14] * 1.0f);       // RK:254
@@ -149,12 +183,12 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, uint32_t bi, v3 
 
 // RK:168-244 traceTLAS.  tstack / bstack: this lane's two LDS stacks.
 template <bool COUNT>
-__device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, v3 o, v3 d, uint32_t* tstack, uint32_t* bstack,
-                                             uint32_t stride, float& traces) {
+__device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& L, v3 o, v3 d, uint32_t* tstack,
+                                             uint32_t* bstack, uint32_t stride, float& traces) {
     TriHit hit; hit.t = 0.0f; hit.u = hit.v = 0.0f; hit.tri = -1; hit.blas = -1;   // RK:170-171
     float nearest = 9999.0f;                                        // RK:172
     const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    NodeR node = load_node(T, 0u);                                  // RK:175
+    NodeR node = load_node_head(T, L, 0u);                          // RK:175
     uint32_t sp = 0;
     for (;;) {                                                      // RK:179
         const uint32_t count = u32f(node.count);                    // RK:180
@@ -162,7 +196,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, v3 o, v3 d, ui
         if (count == 0u) {                                          // RK:183
             if (COUNT) traces += 2.0f;                              // HK:143
             uint32_t i2 = left + 1u;
-            const NodeR c1 = load_node(T, left), c2 = load_node(T, left + 1u);
+            const NodeR c1 = load_node_head(T, L, left), c2 = load_node_head(T, L, left + 1u);
             float d1 = hit_aabb(o, inv, c1);                        // RK:186
             float d2 = hit_aabb(o, inv, c2);                        // RK:187
             const bool swap = d1 > d2;                              // RK:190-196
@@ -170,7 +204,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, v3 o, v3 d, ui
             if (d1 > nearest) {                                     // RK:198
                 if (sp == 0u) break;
                 sp -= 1u;
-                node = load_node(T, tstack[sclamp(sp) * stride]);
+                node = load_node_head(T, L, tstack[sclamp(sp) * stride]);
             } else {
                 node = swap ? c2 : c1;                              // RK:208
                 if (d2 < nearest) {                                 // RK:209
@@ -186,11 +220,11 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, v3 o, v3 d, ui
                 if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
                 uint32_t bi = u32f(T.blas_lookup[li]);              // RK:223
                 if (bi >= T.n_blas) bi = T.n_blas - 1u;
-                trace_blas<COUNT>(T, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
+                trace_blas<COUNT>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
             }
             if (sp == 0u) break;                                    // RK:233
             sp -= 1u;
-            node = load_node(T, tstack[sclamp(sp) * stride]);       // RK:237-238
+            node = load_node_head(T, L, tstack[sclamp(sp) * stride]);       // RK:237-238
         }
     }
     return hit;
@@ -240,6 +274,9 @@ __global__ __launch_bounds__(64 * WAVES) void trace_triangles(const RtFrameArgs 
     uint32_t* tstack = stacks + threadIdx.x;
     uint32_t* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
     constexpr uint32_t stride = 64 * WAVES;
+    __shared__ float4 s_nodes[2 * kLdsNodes];
+    __shared__ float s_blas[20 * kLdsBlas];
+    const TriLds L = stage_head<WAVES>(T, s_nodes, s_blas);
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * (8u * WAVES) + wave * 8u + (lane & 7u);
@@ -256,7 +293,7 @@ __global__ __launch_bounds__(64 * WAVES) void trace_triangles(const RtFrameArgs 
     v3 ro = sc.cameraPos, rd = dir0;
     float affect = 1.0f, sum = 0.0f;
     for (uint32_t bounce = 0; bounce < sc.bounces; ++bounce) {                       // RK:113
-        const TriHit h = trace_tlas<false>(T, ro, rd, tstack, bstack, stride, dummy); // RK:114
+        const TriHit h = trace_tlas<false>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
         ++nrays;
         const bool hit = h.tri >= 0;
         if (bounce == 0) dist = hit ? h.t : 0.0f;                                    // RK:116-118
@@ -272,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES) void trace_triangles(const RtFrameArgs 
         // RK:146-166
         const v3 sdir = normalize(sub(ro, sc.lightPos));
         const float distance = length(sdir);
-        const TriHit sh = trace_tlas<false>(T, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
+        const TriHit sh = trace_tlas<false>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
         ++nrays;
         const float intensity = light_term(sc, ro, s.normal, sdir, distance, sh.tri >= 0, sh.t);
         const v3 diffuseColor = scale(s.w, s.rgb);                                   // RK:133
@@ -294,6 +331,9 @@ __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArg
     uint32_t* tstack = stacks + threadIdx.x;
     uint32_t* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
     constexpr uint32_t stride = 64 * WAVES;
+    __shared__ float4 s_nodes[2 * kLdsNodes];
+    __shared__ float s_blas[20 * kLdsBlas];
+    const TriLds L = stage_head<WAVES>(T, s_nodes, s_blas);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * (8u * WAVES) + wave * 8u + (lane & 7u);
     const uint32_t row = lane >> 3;
@@ -302,7 +342,7 @@ __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArg
     const Scene sc = unpack_scene(A);
     const v3 dir0 = primary_dir(A, sc, x, y);                                        // HK:66-76
     float traces = 0.0f;
-    (void)trace_tlas<true>(T, sc.cameraPos, dir0, tstack, bstack, stride, traces);   // HK:96-99, one bounce
+    (void)trace_tlas<true>(T, L, sc.cameraPos, dir0, tstack, bstack, stride, traces);   // HK:96-99, one bounce
     const float g = clampf(traces / 300.0f, 0.0f, 1.0f);                             // HK:79
     const uint32_t q = unorm8(g * 1.0f);                                             // HK:81-82
     const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;
