@@ -46,6 +46,8 @@ uint32_t tiles_total(uint32_t H) { return (H + 7u) / 8u; }
 // frame, 0.45 of 0.8 ms when 8 ranks share the frame).  Frames in flight each take a share of the
 // chip (RtFrameArgs::grid_share), so one frame's tail runs beside the others' bulk.
 constexpr int kStreams = 4;
+constexpr size_t kCounterBytes = (size_t)RT_RAY_COUNTERS * RT_RAY_COUNTER_STRIDE;   // partial ray counters of one frame
+constexpr size_t kCtrlBytes = kCounterBytes + 32u;                                   // + the 32-byte control block
 
 struct rt_ctx {
     int device = 0;
@@ -84,10 +86,12 @@ struct rt_ctx {
     uint8_t* d_out = nullptr;              // colour buffer of the LATEST rt_render (one of d_outs)
     uint8_t* d_outs[kStreams] = {nullptr};
     size_t out_bytes = 0;
-    unsigned long long* d_rays = nullptr;  // per frame in flight a 32-byte control block: rays (u64), queue count, queue head, pixel / tile-pair cursor
+    // per frame in flight: RT_RAY_COUNTERS partial ray counters (kCtrlBytes - 32 bytes), then a 32-byte
+    // control block: unused u64, queue count, queue head, pixel / tile-pair cursor
+    unsigned long long* d_rays = nullptr;
     float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
     size_t queue_cap = 0;                  // entries
-    unsigned long long* h_rays = nullptr;  // pinned
+    unsigned long long* h_rays = nullptr;  // pinned copy of the partial counters, per frame in flight
     // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
     struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };
     DevBuf d_tri, d_nodes, d_blas, d_tri_lookup, d_blas_lookup, d_tex;
@@ -139,13 +143,13 @@ int rt_create(int device, rt_ctx** out) {
         err = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
     }
     if (err != hipSuccess ||
-        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), 32u * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
-        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), sizeof(unsigned long long) * RT355_MAX_IN_FLIGHT,
+        (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), kCtrlBytes * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
+        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), kCounterBytes * RT355_MAX_IN_FLIGHT,
                              hipHostMallocDefault)) != hipSuccess) {
         rt_destroy(c);
         return fail_hip(err, "rt_create: stream/event/counter setup");
     }
-    for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) c->h_rays[i] = 0;
+    std::memset(c->h_rays, 0, kCounterBytes * RT355_MAX_IN_FLIGHT);
     *out = c;
     return RT_OK;
 }
@@ -540,11 +544,12 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         fa.grid_share = distinct;
     }
 
-    unsigned long long* ctrl = c->d_rays + 4u * slot;          // this frame's 32-byte control block
-    RT_HIP(hipMemsetAsync(ctrl, 0, 32, s));
+    unsigned long long* counters = c->d_rays + (kCtrlBytes / 8u) * slot;   // this frame's partial ray counters ...
+    unsigned long long* ctrl = counters + kCounterBytes / 8u;              // ... and its 32-byte control block
+    RT_HIP(hipMemsetAsync(counters, 0, kCtrlBytes, s));
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
     fa.out = dst;
-    fa.rays = ctrl;
+    fa.rays = counters;
     fa.queue = c->d_queue;
     fa.qctrl = reinterpret_cast<uint32_t*>(ctrl) + 2;
     fa.queue_cap = (uint32_t)c->queue_cap;
@@ -573,7 +578,7 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
-    RT_HIP(hipMemcpyAsync(c->h_rays + slot, ctrl, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    RT_HIP(hipMemcpyAsync(c->h_rays + (kCounterBytes / 8u) * slot, counters, kCounterBytes, hipMemcpyDeviceToHost, s));
     RT_HIP(hipEventRecord(c->ev_done[slot], s));
     c->in_flight = slot + 1;
     return RT_OK;
@@ -604,7 +609,9 @@ int rt_wait(rt_ctx* c) {
     for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipEventSynchronize(c->ev_done[i]));
     if (c->in_flight) {
         c->stats.frames += c->in_flight;
-        c->stats.rays = c->h_rays[c->in_flight - 1u];
+        c->stats.rays = 0;
+        for (uint32_t k = 0; k < RT_RAY_COUNTERS; ++k)
+            c->stats.rays += c->h_rays[(kCounterBytes / 8u) * (c->in_flight - 1u) + k * (RT_RAY_COUNTER_STRIDE / 8u)];
         c->stats.batch_frames = c->in_flight;
         c->stats.batch_kernel_ms = 0.0f;
         for (uint32_t i = 0; i < c->in_flight; ++i) {

@@ -139,14 +139,19 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// one atomicAdd per wave for the scene-traversal counter
+// One atomicAdd per wave for the scene-traversal counter -- spread over RT_RAY_COUNTERS partial
+// counters 256 B apart (the host adds them up): atomics on ONE address complete about 12 ns apart,
+// and a 4K frame of the triangle kernels ends 129,600 waves, each with its atomic: 1.57 ms, which
+// WAS the frame time of those kernels whatever else changed.
 __device__ __forceinline__ void count_rays(unsigned long long* counter, uint32_t nrays) {
+    const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    unsigned long long* part = counter + (size_t)(wave_id % RT_RAY_COUNTERS) * (RT_RAY_COUNTER_STRIDE / 8u);
     const uint64_t live = __ballot(1);
     if (live == ~0ull) {
         const uint32_t tot = wave_sum(nrays);
-        if ((threadIdx.x & 63u) == 0) atomicAdd(counter, (unsigned long long)tot);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(part, (unsigned long long)tot);
     } else {
-        atomicAdd(counter, (unsigned long long)nrays);
+        atomicAdd(part, (unsigned long long)nrays);
     }
 }
 

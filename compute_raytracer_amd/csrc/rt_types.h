@@ -15,6 +15,11 @@
 #define RT_FILTER_SCALE2 1208925819614629174706176.0f    // 2^80
 #define RT_FILTER_UNSCALE 9.094947017729282379150390625e-13f   // 2^-40
 
+// The ray counter of a frame is RT_RAY_COUNTERS partial sums, RT_RAY_COUNTER_STRIDE bytes apart
+// (rt_device.h: count_rays); the host adds them.
+#define RT_RAY_COUNTERS 32u
+#define RT_RAY_COUNTER_STRIDE 256u
+
 // One frame's launch arguments (kernarg segment -> SGPRs; everything here is wave-uniform).
 struct RtFrameArgs {
     float p[24];               // SceneParameters as RR:157-165 packs them
@@ -40,7 +45,7 @@ struct RtFrameArgs {
     const uint8_t* face[6];    // cube faces, rgba8unorm
     uint32_t fw[6], fh[6];
     uint8_t* out;              // compact tile buffer [n_local_tiles*8][W][4]
-    unsigned long long* rays;  // scene-traversal counter (one atomicAdd per wave)
+    unsigned long long* rays;  // scene-traversal counter: RT_RAY_COUNTERS partial sums (one atomicAdd per wave)
     // path queue between the first-bounce kernel and the path kernel (two-kernel pipeline):
     // 3 float4 per surviving path {ro.xyz, pixel index}, {rd.xyz, dist}, {color.rgb, 0}
     float4* queue;             // [queue_cap][3]
