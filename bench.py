@@ -239,7 +239,7 @@ def main():
             kernel_label = "trace_pixels<FILTER=false> (literal loop)"
         elif hierarchy:
             kernel_label = "bvh_pixels (bounding-sphere hierarchy, one persistent kernel per frame)"
-        elif N >= 128 and a.variant in (0, 5):
+        elif N >= 320 and a.variant in (0, 5):
             kernel_label = "first_bounce + trace_paths (brute force, one frame's ray-trace launches)"
         else:
             kernel_label = "trace_pixels (brute force, single kernel)"

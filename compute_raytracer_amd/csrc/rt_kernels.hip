@@ -701,7 +701,7 @@ hipError_t launch_fast(const RtFrameArgs& a, int variant, hipStream_t s) {
     if (2 * rec + 8u * 8u * 256u > kLdsCap)                                  // > 4608 spheres: no LDS staging
         return launch_pixels<4, true, false, SGN, false, 16, true>(a, s);
     const bool small = 3 * rec + 3 * (rec / 4) + 8u * 16u * 256u <= 80u * 1024u;      // N <= ~800: 2 workgroups of 8 waves per CU
-    const bool pipeline = a.queue && a.qctrl && a.N >= 128u;
+    const bool pipeline = a.queue && a.qctrl && a.N >= 320u;   // measured crossover of the two brute-force forms
     switch (variant) {
         case 0:   // default: two-kernel pipeline for scenes where the sphere loop dominates,
                   // single kernel for small scenes (the queue round trip costs more than it saves)

@@ -130,7 +130,7 @@ int rt_set_mode(rt_ctx* ctx, int mode);
 
 /* Kernel variant for A/B measurements (0 = library default).  Fast-mode sphere scenes:
  * 0 = bounding-sphere hierarchy from 128 spheres on, single brute-force kernel below;
- * 4 = hierarchy for any sphere count; 5 = brute force (two-kernel pipeline from 128 spheres on);
+ * 4 = hierarchy for any sphere count; 5 = brute force (two-kernel pipeline from 320 spheres on);
  * 1, 2, 3 = individual brute-force forms.  Every variant produces the same pixels.  See DESIGN.md. */
 int rt_set_variant(rt_ctx* ctx, int variant);
 
