@@ -237,6 +237,9 @@ int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_resize: ctx is NULL");
     if (width == 0 || height == 0 || width > 65536u || height > 65536u)
         return fail(RT_ERR_INVALID_ARG, "rt_resize: width/height must be in 1..65536");
+    // pixel indices and the padded tile space are 32-bit in the kernels
+    if ((uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u >= (1ull << 31))
+        return fail(RT_ERR_INVALID_ARG, "rt_resize: more than 2^31 pixel slots (width x height, padded to 8x8 tiles)");
     RT_HIP(hipSetDevice(c->device));
     { int rc = drain(c); if (rc != RT_OK) return rc; }
     c->W = width;

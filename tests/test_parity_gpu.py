@@ -225,6 +225,7 @@ def test_call_order_and_capacity_errors():
     try:
         assert L.rt_render(ctx) == abi.RT_ERR_STATE and b"rt_resize" in L.rt_last_error(ctx)
         assert L.rt_resize(ctx, 0, 5) == abi.RT_ERR_INVALID_ARG
+        assert L.rt_resize(ctx, 65536, 65536) == abi.RT_ERR_INVALID_ARG and b"2^31" in L.rt_last_error(ctx)
         abi.check(L.rt_resize(ctx, 16, 16), ctx)
         assert L.rt_render(ctx) == abi.RT_ERR_STATE and b"rt_write_params" in L.rt_last_error(ctx)
         p = np.zeros(24, np.float32)
