@@ -91,7 +91,8 @@ int rt_abi_version(void);
 /* ---- resources ----------------------------------------------------------------------- */
 
 /* Replaces createTexture({size:{width,height}, format:'rgba8unorm'}) (RR:102-109): the
- * W x H x 4 B colour buffer, row-major, row 0 = top.  Re-callable. */
+ * W x H x 4 B colour buffer, row-major, row 0 = top.  Re-callable.  1 <= W, H <= 65536 and
+ * fewer than 2^31 pixels (padded to 8x8 tiles). */
 int rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height);
 
 /* Replaces queue.writeBuffer(sceneParameters, 0, Float32Array(24)) (RR:157-165).
