@@ -200,3 +200,65 @@ def test_frames_in_flight_with_a_moving_camera(oracle):
         r.enqueue()
     assert np.array_equal(r.read_pixels(), refs[8][0])
     r.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_call_sequences_with_frames_in_flight(seed):
+    """Random interleavings of parameter writes, variant / mode switches, rt_render, rt_render_to on
+    rotating streams, waits and read-backs: every frame must be the one its parameters describe,
+    whatever was in flight when it was enqueued (hierarchy frames overlap, brute-force and literal
+    frames re-run the per-frame preparation and are ordered behind the frames in flight)."""
+    import torch
+    rng = np.random.default_rng(700 + seed)
+    scene = rt.SceneRaytracing().createScene(synthetic_spheres(220, 31 + seed))
+    W, H, B = 192, 120, 4
+    cams = [[0.06 + 0.5 * k, 2.7 + 0.2 * k, 3.3 - 0.4 * k] for k in range(4)]
+
+    def set_cam(k):
+        scene.camera.position = cams[k]
+        scene.camera.update()
+        scene.light.position = [0.7 * k, 5.0, -0.4 * k]
+
+    ref = []
+    for k in range(4):                       # reference frames: literal kernel, one at a time
+        set_cam(k)
+        img, _ = gpu_render(scene, W, H, B, strict=True)
+        ref.append(img)
+
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    bufs = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(6)]
+    torch.cuda.synchronize()
+    last_render_cam = None                   # camera of the latest rt_render
+    pending = {}                             # buffer index -> camera index of the frame rendered into it
+    cam = 0
+    set_cam(cam)
+    for step in range(70):
+        op = rng.choice(["cam", "variant", "mode", "render", "render", "render_to", "render_to", "wait", "read"])
+        if op == "cam":
+            cam = int(rng.integers(0, 4)); set_cam(cam)
+        elif op == "variant":
+            r.set_variant(int(rng.choice([0, 1, 4, 5])))
+        elif op == "mode":
+            r.set_mode(bool(rng.integers(0, 2)))
+        elif op == "render":
+            r.recalculateScene(); r.enqueue(); last_render_cam = cam
+        elif op == "render_to":
+            free = [i for i in range(len(bufs)) if i not in pending]
+            if free:
+                i = free[0]
+                r.render_to(bufs[i].data_ptr(), bufs[i].numel(), streams[int(rng.integers(0, 4))].cuda_stream)
+                pending[i] = cam
+        elif op == "wait" or op == "read":
+            r.wait()
+            torch.cuda.synchronize()
+            for i, k in pending.items():
+                assert np.array_equal(bufs[i].cpu().numpy().reshape(H, W, 4), ref[k]), (seed, step, "render_to", i, k)
+            pending.clear()
+            if op == "read" and last_render_cam is not None:
+                assert np.array_equal(r.read_pixels(), ref[last_render_cam]), (seed, step, "read", last_render_cam)
+    r.wait()
+    torch.cuda.synchronize()
+    for i, k in pending.items():
+        assert np.array_equal(bufs[i].cpu().numpy().reshape(H, W, 4), ref[k]), (seed, "final", i, k)
+    r.close()
