@@ -54,7 +54,7 @@ struct rt_ctx {
     hipStream_t stream = nullptr;        // uploads, read-back, and frames 0, 3, 6 ... of rt_render (= streams[0])
     hipStream_t streams[kStreams] = {nullptr};   // rt_render rotates: consecutive frames may overlap on the device
     hipEvent_t ev_prep0[RT355_MAX_IN_FLIGHT] = {nullptr}, ev_k0[RT355_MAX_IN_FLIGHT] = {nullptr},
-               ev_k1[RT355_MAX_IN_FLIGHT] = {nullptr}, ev_done[RT355_MAX_IN_FLIGHT] = {nullptr};
+               ev_k1[RT355_MAX_IN_FLIGHT] = {nullptr};
     hipEvent_t ev_scene = nullptr;       // the scene arrays / hierarchy a frame reads are complete ...
     hipStream_t scene_stream = nullptr;  // ... recorded on this stream
     uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
@@ -91,7 +91,7 @@ struct rt_ctx {
     unsigned long long* d_rays = nullptr;
     float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
     size_t queue_cap = 0;                  // entries
-    unsigned long long* h_rays = nullptr;  // pinned copy of the partial counters, per frame in flight
+    unsigned long long* h_rays = nullptr;  // pinned copy of the latest frame's partial counters
     // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
     struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };
     DevBuf d_tri, d_nodes, d_blas, d_tri_lookup, d_blas_lookup, d_tex;
@@ -139,17 +139,17 @@ int rt_create(int device, rt_ctx** out) {
     for (int i = 0; i < RT355_MAX_IN_FLIGHT && err == hipSuccess; ++i) {
         if ((err = hipEventCreate(&c->ev_prep0[i])) != hipSuccess) break;
         if ((err = hipEventCreate(&c->ev_k0[i])) != hipSuccess) break;
-        if ((err = hipEventCreate(&c->ev_k1[i])) != hipSuccess) break;
-        err = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
+        err = hipEventCreate(&c->ev_k1[i]);
     }
     if (err != hipSuccess ||
         (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), kCtrlBytes * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
-        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), kCounterBytes * RT355_MAX_IN_FLIGHT,
+        (err = hipMemset(c->d_rays, 0, kCtrlBytes * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
+        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), kCounterBytes,
                              hipHostMallocDefault)) != hipSuccess) {
         rt_destroy(c);
         return fail_hip(err, "rt_create: stream/event/counter setup");
     }
-    std::memset(c->h_rays, 0, kCounterBytes * RT355_MAX_IN_FLIGHT);
+    std::memset(c->h_rays, 0, kCounterBytes);
     *out = c;
     return RT_OK;
 }
@@ -157,7 +157,7 @@ int rt_create(int device, rt_ctx** out) {
 int rt_destroy(rt_ctx* c) {
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
-    for (uint32_t i = 0; i < c->in_flight; ++i) (void)hipEventSynchronize(c->ev_done[i]);
+    for (uint32_t i = 0; i < c->in_flight; ++i) (void)hipEventSynchronize(c->ev_k1[i]);
     for (int k = 0; k < kStreams; ++k)
         if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
     (void)hipFree(c->d_records);
@@ -175,7 +175,6 @@ int rt_destroy(rt_ctx* c) {
         if (c->ev_prep0[i]) (void)hipEventDestroy(c->ev_prep0[i]);
         if (c->ev_k0[i]) (void)hipEventDestroy(c->ev_k0[i]);
         if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]);
-        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
     }
     if (c->ev_scene) (void)hipEventDestroy(c->ev_scene);
     for (int k = 0; k < kStreams; ++k)
@@ -547,9 +546,10 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         fa.grid_share = distinct;
     }
 
-    unsigned long long* counters = c->d_rays + (kCtrlBytes / 8u) * slot;   // this frame's partial ray counters ...
-    unsigned long long* ctrl = counters + kCounterBytes / 8u;              // ... and its 32-byte control block
-    RT_HIP(hipMemsetAsync(counters, 0, kCtrlBytes, s));
+    // this frame's partial ray counters and its 32-byte control block: one of RT355_MAX_IN_FLIGHT
+    // sets, all zeroed by rt_create and again by rt_wait (no per-frame memset or read-back)
+    unsigned long long* counters = c->d_rays + (kCtrlBytes / 8u) * slot;
+    unsigned long long* ctrl = counters + kCounterBytes / 8u;
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
     fa.out = dst;
     fa.rays = counters;
@@ -581,8 +581,6 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
-    RT_HIP(hipMemcpyAsync(c->h_rays + (kCounterBytes / 8u) * slot, counters, kCounterBytes, hipMemcpyDeviceToHost, s));
-    RT_HIP(hipEventRecord(c->ev_done[slot], s));
     c->in_flight = slot + 1;
     return RT_OK;
 }
@@ -609,12 +607,16 @@ int rt_render_to(rt_ctx* c, void* device_dst, size_t cap, void* hip_stream) {
 int rt_wait(rt_ctx* c) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_wait: ctx is NULL");
     RT_HIP(hipSetDevice(c->device));
-    for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipEventSynchronize(c->ev_done[i]));
+    for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipEventSynchronize(c->ev_k1[i]));
     if (c->in_flight) {
+        // ray count of the latest frame; then the counter sets of this batch are zeroed for the next
+        RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays + (kCtrlBytes / 8u) * (c->in_flight - 1u), kCounterBytes,
+                              hipMemcpyDeviceToHost, c->stream));
+        RT_HIP(hipMemsetAsync(c->d_rays, 0, kCtrlBytes * c->in_flight, c->stream));
+        RT_HIP(hipStreamSynchronize(c->stream));
         c->stats.frames += c->in_flight;
         c->stats.rays = 0;
-        for (uint32_t k = 0; k < RT_RAY_COUNTERS; ++k)
-            c->stats.rays += c->h_rays[(kCounterBytes / 8u) * (c->in_flight - 1u) + k * (RT_RAY_COUNTER_STRIDE / 8u)];
+        for (uint32_t k = 0; k < RT_RAY_COUNTERS; ++k) c->stats.rays += c->h_rays[k * (RT_RAY_COUNTER_STRIDE / 8u)];
         c->stats.batch_frames = c->in_flight;
         c->stats.batch_kernel_ms = 0.0f;
         for (uint32_t i = 0; i < c->in_flight; ++i) {
