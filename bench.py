@@ -228,7 +228,10 @@ def main():
         flops_launch = FLOP_PER_TEST * N * rays_kernel
         # launches of consecutive frames overlap on the device (each on a share of the chip), so the
         # chip-level rate is flops per launch / frame period; one frame at a time: / the launch duration
-        overlapping = hierarchy and not a.serial          # the brute-force forms share a path queue: serialised
+        # the two-kernel brute-force pipeline shares a path queue: its frames are serialised (rt_api.hip)
+        queue_pipeline = (a.mode == "fast" and not hierarchy and
+                          (a.variant in (2, 3) or (a.variant in (0, 4, 5) and N >= 320)))
+        overlapping = not a.serial and not queue_pipeline
         in_flight = FLIGHT if overlapping else 1
         roof_ms = ms_per_step if overlapping else kernel_ms
         achieved_tf = flops_launch / (roof_ms * 1e-3) / 1e12

@@ -454,9 +454,14 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
                          (c->variant == 4 || (c->variant == 0 && c->n >= 128u));
     // Frames in flight: the hierarchy kernel and the triangle kernels write nothing but their
     // own control block and `dst`, so consecutive frames may overlap on the device (the next
-    // frame's workgroups start while the last paths of this one finish); the brute-force
-    // pipeline shares one path queue and is serialised behind the frames in flight.
-    const bool overlap_ok = tri || use_bvh;
+    // frame's workgroups start while the last paths of this one finish), and so may the
+    // single-kernel brute-force and literal forms; the two-kernel brute-force pipeline shares one
+    // path queue and is serialised behind the frames in flight.
+    // (rt_kernels.hip: launch_fast -- variants 2 and 3 force the pipeline, 0 / 5 take it from 320 spheres on)
+    const bool queue_pipeline = !tri && !use_bvh && c->mode == RT_MODE_FAST && filter_ok &&
+                                (c->variant == 2 || c->variant == 3 ||
+                                 ((c->variant == 0 || c->variant == 4 || c->variant == 5) && c->n >= 320u));
+    const bool overlap_ok = !queue_pipeline;
     const bool need_prep = !tri && c->n && (!c->prep_spheres_valid || (!use_bvh && !c->prep_params_valid));
     const bool need_bvh = use_bvh && !c->bvh_valid;
 
