@@ -1,0 +1,20 @@
+"""Soak test (development): many frames, every read-back hashed against the golden C3 frame."""
+import os, sys, json, hashlib, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import compute_raytracer_amd as rt
+meta = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "frames.json")))["C3"]
+cfg = rt.BASELINE_CONFIGS["C3"]
+scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
+r = rt.RendererRaytracing(cfg["width"], cfg["height"], scene, maxBounces=cfg["bounces"]).initialize()
+r.recalculateScene()
+bad = 0; t0 = time.time(); frames = 0
+for batch in range(int(sys.argv[1]) if len(sys.argv) > 1 else 150):
+    n = 1 + (batch * 7) % 23
+    for _ in range(n):
+        r.enqueue()
+    img = r.read_pixels(); frames += n
+    ok = hashlib.sha256(img.tobytes()).hexdigest() == meta["sha256"] and r.stats()["rays"] == meta["rays"]
+    bad += not ok
+    if not ok: print("MISMATCH in batch", batch, n, flush=True)
+print("soak: %d frames in %d batches, %.1f s, mismatches %d" % (frames, batch + 1, time.time() - t0, bad))
+r.close()
