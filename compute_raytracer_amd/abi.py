@@ -27,7 +27,7 @@ SYMBOLS = [
     "rt_write_tri_lookup", "rt_write_blas_lookup", "rt_write_mesh_texture", "rt_select_kernel", "rt_set_mode",
     "rt_set_variant", "rt_set_partition", "rt_tiles_of_rank", "rt_padded_tiles", "rt_render", "rt_wait",
     "rt_read_pixels", "rt_get_stats", "rt_render_to", "rt_assemble_frame", "rt_device_pixels",
-    "rt_build_hierarchy",
+    "rt_build_hierarchy", "rt_filter_plan",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
         "rt_assemble_frame": (ctypes.c_int, [vp, vp, vp, u32, vp]),
         "rt_device_pixels": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "rt_build_hierarchy": (ctypes.c_int, [fp, u32, fp, ctypes.POINTER(u32), u32, ctypes.POINTER(u32)]),
+        "rt_filter_plan": (ctypes.c_int, [fp, u32, fp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -38,6 +38,38 @@ int fail_hip(hipError_t e, const char* where) {
 
 uint32_t tiles_total(uint32_t H) { return (H + 7u) / 8u; }
 
+// max(scene bound, |camera|, |light|) with a sticky NaN: any NaN operand makes the reach NaN, which
+// switches both filter forms off (enqueue)
+double rt_reach(double bound, double cam, double lgt) {
+    if (bound != bound || cam != cam || lgt != lgt) return NAN;
+    return std::max(bound, std::max(cam, lgt));
+}
+
+// max over spheres of |center| + |radius|.  A NaN anywhere is sticky -- the bound of a scene with a
+// NaN record is NaN whatever the record's position --, an infinite record gives +inf.
+double rt_scene_bound(const float* records, uint32_t n) {
+    double bound = 0.0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* r = records + 8u * (size_t)i;
+        const double len = std::sqrt((double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2]) + std::fabs((double)r[7]);
+        if (len != len || bound != bound) bound = NAN;
+        else if (len > bound) bound = len;
+    }
+    return bound;
+}
+
+// Which filter forms a frame may use.  reach: bound on |ray origin| and on |center| + radius.  The
+// sign-aware filter is valid only while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays
+// below half of the 0.001 a valid hit needs (rt_filter.h: filter_one); beyond 2^20 (or NaN / inf) the
+// 2^40-scaled filter arithmetic could overflow, and the frame is rendered by the literal kernel.
+void rt_plan(double scene_bound, const float* p, bool& filter_ok, uint32_t& signed_filter) {
+    const double cam = std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
+    const double lgt = std::sqrt((double)p[16] * p[16] + (double)p[17] * p[17] + (double)p[18] * p[18]);
+    const double reach = rt_reach(scene_bound, cam, lgt);
+    filter_ok = reach == reach && reach < 1048576.0;
+    signed_filter = (filter_ok && 2.0 * reach * 7.3e-7 < 5.0e-4) ? 1u : 0u;
+}
+
 }  // namespace
 
 // Frames the library itself keeps concurrent (rt_render rotates over this many streams and colour
@@ -219,10 +251,16 @@ static int ensure_out(rt_ctx* c) {
             c->out_bytes = need;
         }
     }
-    // one queue entry (48 B) per local pixel is the worst case (every primary ray hits)
+    return RT_OK;
+}
+
+// The path queue of the two-kernel brute-force pipeline (48 B per local pixel in the worst case:
+// every primary ray hits) is allocated when a frame first takes that pipeline -- the default
+// hierarchy path never reads it (1.6 GB at 8K).
+static int ensure_queue(rt_ctx* c) {
     const size_t entries = (size_t)rt_padded_tiles(c->H, c->world) * 8u * c->W;
     if (entries > c->queue_cap) {
-        RT_HIP(hipStreamSynchronize(c->stream));
+        { int rc = drain(c); if (rc != RT_OK) return rc; }
         (void)hipFree(c->d_queue);
         c->d_queue = nullptr;
         c->queue_cap = 0;
@@ -289,15 +327,7 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
     c->n16 = (n + 15u) & ~15u;
     c->h_records.assign(records, records + 8u * (size_t)n);   // the hierarchy is built lazily from this copy
     c->bvh_valid = false;
-    {   // scene extent, for the sign-aware filter (rt_kernels.hip: filter_one)
-        double bound = 0.0;
-        for (uint32_t i = 0; i < n; ++i) {
-            const float* r = records + 8u * (size_t)i;
-            const double len = std::sqrt((double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2]) + std::fabs((double)r[7]);
-            if (!(len <= bound)) bound = len;   // NaN propagates into `bound`
-        }
-        c->scene_bound = (float)bound;
-    }
+    c->scene_bound = (float)rt_scene_bound(records, n);   // scene extent, for the filter's validity range (enqueue)
     c->have_spheres = true;
     c->prep_spheres_valid = false;
     return RT_OK;
@@ -432,21 +462,9 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     RT_HIP(hipSetDevice(c->device));
 
     // ---- which kernels render this frame ----
-    // reach: bound on |ray origin| and on |center| + radius.  The sign-aware filter is valid only
-    // while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays below half of the 0.001 a
-    // valid hit needs (rt_filter.h: filter_one); beyond 2^20 (or NaN) the 2^40-scaled filter
-    // arithmetic could overflow, and the frame is rendered by the literal kernel instead.
-    double reach = c->scene_bound;
+    bool filter_ok = false;
     uint32_t signed_filter = 0;
-    {
-        const float* p = c->params;
-        const double cam = std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
-        const double lgt = std::sqrt((double)p[16] * p[16] + (double)p[17] * p[17] + (double)p[18] * p[18]);
-        if (!(cam <= reach)) reach = cam;
-        if (!(lgt <= reach)) reach = lgt;
-        signed_filter = (reach == reach && 2.0 * reach * 7.3e-7 < 5.0e-4) ? 1u : 0u;
-    }
-    const bool filter_ok = reach < 1048576.0;
+    rt_plan(c->scene_bound, c->params, filter_ok, signed_filter);
     // Fast mode renders through the bounding-sphere hierarchy (rt_bvh.hip) from 128 spheres on
     // (default, variant 0; measured crossover against the brute-force kernels ~100 spheres) or
     // whenever variant 4 asks for it; variant 5 is the brute-force default, 1-3 its forms.
@@ -465,6 +483,7 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     const bool need_prep = !tri && c->n && (!c->prep_spheres_valid || (!use_bvh && !c->prep_params_valid));
     const bool need_bvh = use_bvh && !c->bvh_valid;
 
+    if (queue_pipeline) { int rc = ensure_queue(c); if (rc != RT_OK) return rc; }
     if (need_bvh) {   // host build; the device arrays may be reallocated: nothing may be in flight
         int rc = drain(c);
         if (rc != RT_OK) return rc;
@@ -558,9 +577,9 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
     fa.out = dst;
     fa.rays = counters;
-    fa.queue = c->d_queue;
+    fa.queue = queue_pipeline ? c->d_queue : nullptr;   // rt_kernels.hip takes the pipeline only with a queue
     fa.qctrl = reinterpret_cast<uint32_t*>(ctrl) + 2;
-    fa.queue_cap = (uint32_t)c->queue_cap;
+    fa.queue_cap = queue_pipeline ? (uint32_t)c->queue_cap : 0u;
     RtLaunchCfg cfg;
     cfg.mode = filter_ok ? c->mode : (int)RT_MODE_STRICT;
     cfg.variant = (c->variant == 4 || c->variant == 5) ? 0 : c->variant;   // rt_kernels.hip numbers its default 0
@@ -692,6 +711,16 @@ int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* 
     if (cap_nodes < nodes + 1u || !rec4 || !link) return fail(RT_ERR_CAPACITY, "rt_build_hierarchy: need n_nodes + 1 entries");
     std::memcpy(rec4, r.data(), r.size() * sizeof(float));
     std::memcpy(link, l.data(), l.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+int rt_filter_plan(const float* records, uint32_t n, const float params[24], int* filter_ok, int* signed_filter) {
+    if ((n && !records) || !params || !filter_ok || !signed_filter) return fail(RT_ERR_INVALID_ARG, "rt_filter_plan: NULL argument");
+    bool ok = false;
+    uint32_t sgn = 0;
+    rt_plan((double)(float)rt_scene_bound(records, n), params, ok, sgn);
+    *filter_ok = ok ? 1 : 0;
+    *signed_filter = (int)sgn;
     return RT_OK;
 }
 

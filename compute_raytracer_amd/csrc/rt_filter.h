@@ -90,12 +90,36 @@ __device__ __forceinline__ float sq_acc(float x, float c) {           // x*x + c
 __device__ __forceinline__ float sq_sub(float x, float r) {           // x*x - r
     float d; asm("v_fma_f32 %0, %1, %1, -%2" : "=v"(d) : "v"(x), "v"(r)); return d;
 }
-// clamp(b*b - c) to [0,1]: exactly 1.0 when the 2^80-scaled discriminant is positive (then it
-// is >= 1: b*b and c are either both integers -- |c| >= 2^24 whenever c != 0, because c is
-// the rounded difference of numbers of magnitude 2^80 |oc|^2 --, or c == 0 and b*b < 1 needs
-// |h.oc| < 2^-40 at the same time: a double coincidence of measure zero), else 0.0
+// ---- candidate mask of a 16-sphere batch ----------------------------------------------------------------
+// RT_MASK_SIGNBITS=1 (default): the mask is built from the SIGN BIT of each filter discriminant,
+// shifted in with one v_alignbit_b32 per sphere: code = (code << 1) | sign(x).  A sphere is a
+// candidate unless x is negative (x == +0 counts as a candidate: conservative).  Exact for every
+// input -- there is no value of x that can disturb a neighbouring bit.
+// RT_MASK_SIGNBITS=0: the round-1 form, kept for A/B timing only: the `clamp` modifier of the FMA
+// that forms x yields 1.0 / 0.0 and code = 2*code + dd is one more FMA.  That form has a hole:
+// 0 < x < 1 (the 2^80-scaled discriminant of a ray that grazes the inflated sphere to within
+// 2^-40, constructible: tests/test_filter_fraction_gpu.py) leaves a FRACTION in the sum, whose
+// carries can clear the bit of another sphere of the batch.
+#ifndef RT_MASK_SIGNBITS
+#define RT_MASK_SIGNBITS 1
+#endif
+#if RT_MASK_SIGNBITS
+typedef uint32_t mask_acc;
+__device__ __forceinline__ mask_acc mask_zero() { return 0u; }
+__device__ __forceinline__ mask_acc shift_in(mask_acc code, float x) {   // (code << 1) | (x < 0 or -0)
+    return __builtin_amdgcn_alignbit(code, __float_as_uint(x), 31u);
+}
+__device__ __forceinline__ uint32_t mask_bits(mask_acc code) { return code ^ 0xFFFFu; }   // after 16 shift_in: bit (15-k) = sphere k may be hit
+#else
+typedef float mask_acc;
+__device__ __forceinline__ mask_acc mask_zero() { return 0.0f; }
+__device__ __forceinline__ uint32_t mask_bits(mask_acc code) { return (uint32_t)code; }
+#endif
 template <bool SGN>
 __device__ __forceinline__ float disc_ind(float b, float c) {
+#if RT_MASK_SIGNBITS
+    return SGN ? __builtin_fmaf(-b, __builtin_fabsf(b), -c) : __builtin_fmaf(b, b, -c);   // the raw discriminant
+#endif
 #if RT_CLAMP_BUILTIN
     return __builtin_amdgcn_fmed3f(SGN ? __builtin_fmaf(-b, __builtin_fabsf(b), -c) : __builtin_fmaf(b, b, -c), 0.0f, 1.0f);
 #endif
@@ -104,12 +128,14 @@ __device__ __forceinline__ float disc_ind(float b, float c) {
     else     asm("v_fma_f32 %0, %1, %1, -%2 clamp" : "=v"(d) : "v"(b), "v"(c));      // b*b - c
     return d;
 }
+#if !RT_MASK_SIGNBITS
 __device__ __forceinline__ float shift_in(float code, float bit) {    // 2*code + bit
 #if RT_FMA_BUILTIN
     return __builtin_fmaf(code, 2.0f, bit);
 #endif
     float d; asm("v_fma_f32 %0, %1, 2.0, %2" : "=v"(d) : "v"(code), "v"(bit)); return d;
 }
+#endif
 
 // Conservative test "can sphere s have discriminant > 0 (and lie in front of the origin)".
 // With h = d/|d| the reference's condition b^2 - 4a*c > 0 (HK:311,316) is (h.oc)^2 - c > 0.  The
@@ -155,7 +181,10 @@ __device__ __forceinline__ float sq_signed_minus(float b, float q) {     // b*b 
 __device__ __forceinline__ float opaque_negone() {
     float x; asm volatile("v_mov_b32 %0, -1.0" : "=v"(x)); return x;
 }
-__device__ __forceinline__ float sub_clamp(float e, float c, float negone) {   // clamp(e - c)
+__device__ __forceinline__ float sub_clamp(float e, float c, float negone) {   // clamp(e - c); sign-bit masks: e - c
+#if RT_MASK_SIGNBITS
+    return __builtin_fmaf(c, negone, e);    // negone is opaque: stays a v_fma_f32
+#endif
 #if RT_CLAMP_BUILTIN
     return __builtin_amdgcn_fmed3f(__builtin_fmaf(c, negone, e), 0.0f, 1.0f);
 #endif

@@ -97,7 +97,7 @@ __device__ __forceinline__ void trace_filtered(const float4* __restrict__ F, con
 #pragma unroll
     for (int k = 0; k < 8; ++k) g[k] = F[k];
     for (uint32_t s = 0; s < N16; s += 16u) {
-        float code = 0.0f;
+        mask_acc code = mask_zero();
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             float4 gn[8];
@@ -109,8 +109,9 @@ __device__ __forceinline__ void trace_filtered(const float4* __restrict__ F, con
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] = gn[k];
         }
-        if (code > 0.0f) {
-            cl.slot[cnt * 64u] = (s << 16) | (uint32_t)code;
+        const uint32_t bits = mask_bits(code);
+        if (bits != 0u) {
+            cl.slot[cnt * 64u] = (s << 16) | bits;
             ++cnt;
         }
         if (__ballot(cnt >= (uint32_t)CAP) != 0ull) drain();
@@ -167,7 +168,7 @@ __device__ __forceinline__ void trace_hoisted_pair(const float4* __restrict__ F,
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[k] = F[k];
     for (uint32_t s = 0; s < N16; s += 16u) {
-        float code0 = 0.0f, code1 = 0.0f;
+        mask_acc code0 = mask_zero(), code1 = mask_zero();
 #pragma unroll
         for (int quarter = 0; quarter < 4; ++quarter) {
             float4 gn[4];
@@ -181,12 +182,13 @@ __device__ __forceinline__ void trace_hoisted_pair(const float4* __restrict__ F,
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = gn[k];
         }
-        if (act0 && code0 > 0.0f) {
-            slot0[cnt0 * 64u] = (s << 16) | (uint32_t)code0;
+        const uint32_t bits0 = mask_bits(code0), bits1 = mask_bits(code1);
+        if (act0 && bits0 != 0u) {
+            slot0[cnt0 * 64u] = (s << 16) | bits0;
             ++cnt0;
         }
-        if (act1 && code1 > 0.0f) {
-            slot1[cnt1 * 64u] = (s << 16) | (uint32_t)code1;
+        if (act1 && bits1 != 0u) {
+            slot1[cnt1 * 64u] = (s << 16) | bits1;
             ++cnt1;
         }
         if (__ballot(cnt0 >= (uint32_t)CAP || cnt1 >= (uint32_t)CAP) != 0ull) {

@@ -202,6 +202,13 @@ int rt_device_pixels(rt_ctx* ctx, void** out_ptr, size_t* out_bytes);
 int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* link, uint32_t cap_nodes,
                        uint32_t* n_nodes);
 
+/* Which filter forms a frame of this scene may use (no device needed): *filter_ok = 0 when
+ * max(|center| + |radius| over the spheres, |cameraPos|, |lightPosition|) is NaN, infinite or
+ * >= 2^20 -- fast mode then renders the frame with the literal kernel --, *signed_filter = 1 when
+ * that reach is below 342 (the sign-aware filter and hierarchy walk).  A NaN in ANY record, whatever
+ * its position, switches both off. */
+int rt_filter_plan(const float* records, uint32_t n, const float params[24], int* filter_ok, int* signed_filter);
+
 #ifdef __cplusplus
 }
 #endif

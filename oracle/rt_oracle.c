@@ -137,16 +137,94 @@ uint8_t rt_oracle_unorm8(float c) {
     return (uint8_t)floorf(c * 255.0f + 0.5f);
 }
 
-static inline v3 texel(const rt_oracle_face* f, int x, int y) {
-    if (x < 0) x = 0;
-    if (y < 0) y = 0;
-    if (x > (int)f->w - 1) x = (int)f->w - 1;
-    if (y > (int)f->h - 1) y = (int)f->h - 1;
+static inline v3 texel_at(const rt_oracle_face* f, int x, int y) {
     const uint8_t* p = f->rgba + 4u * ((size_t)y * f->w + (size_t)x);
     return V((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f);
 }
 
+static inline v3 texel(const rt_oracle_face* f, int x, int y) {   /* clamp-to-edge inside one image */
+    if (x < 0) x = 0;
+    if (y < 0) y = 0;
+    if (x > (int)f->w - 1) x = (int)f->w - 1;
+    if (y > (int)f->h - 1) y = (int)f->h - 1;
+    return texel_at(f, x, y);
+}
+
 static inline v3 lerp3(v3 a, v3 b, float f) { return add(a, scale(f, sub(b, a))); }
+
+/* A WebGPU cube texture is six SQUARE layers of one size (a 'cube' view needs width == height and
+ * 6 array layers), and linear filtering is seamless across its faces on every backend WebGPU runs
+ * on (Vulkan 1.3 "Cube Map Edge Handling": a texel beyond an edge of the selected face is taken
+ * from the adjacent face; D3D12 and Metal do the same; a sampler's address modes do not apply to
+ * the face-local coordinates of a cube lookup).  The C ABI accepts any six images; when they are not
+ * six equal squares the lookup is not a valid WebGPU cube and stays inside the selected face
+ * (clamp to edge). */
+static int cube_is_seamless(const rt_oracle_face faces[6]) {
+    for (int i = 0; i < 6; ++i)
+        if (faces[i].w != faces[0].w || faces[i].h != faces[0].w) return 0;
+    return 1;
+}
+
+/* Texel (i, j) of `face`, i or j (not both) one step outside [0, n): the texel of the adjacent face
+ * that touches the crossed edge at the same position along it.  Integer geometry, exact: texel
+ * centres in units of 1/n with the face planes at +-n are S = 2i+1-n, T = 2j+1-n (|.| <= n-1 inside,
+ * n+1 one step outside); the 3-D point of that centre (rows of Vulkan's face table solved for
+ * x,y,z) is folded over the edge -- the coordinate that left the cube is clamped to +-n and becomes
+ * the major axis, the old major axis drops to +-(n-1), the third coordinate stays -- and read back
+ * through the table of the new face. */
+static void cube_fold(int face, int i, int j, int n, int* nf, int* ni, int* nj) {
+    const int S = 2 * i + 1 - n, T = 2 * j + 1 - n;
+    int p[3];   /* x, y, z */
+    switch (face) {
+        case 0: p[0] = n;  p[1] = -T; p[2] = -S; break;   /* +X: sc = -z, tc = -y */
+        case 1: p[0] = -n; p[1] = -T; p[2] = S;  break;   /* -X: sc = +z, tc = -y */
+        case 2: p[0] = S;  p[1] = n;  p[2] = T;  break;   /* +Y: sc = +x, tc = +z */
+        case 3: p[0] = S;  p[1] = -n; p[2] = -T; break;   /* -Y: sc = +x, tc = -z */
+        case 4: p[0] = S;  p[1] = -T; p[2] = n;  break;   /* +Z: sc = +x, tc = -y */
+        default: p[0] = -S; p[1] = -T; p[2] = -n; break;  /* -Z: sc = -x, tc = -y */
+    }
+    const int major = face >> 1;
+    int out = 0;
+    for (int a = 0; a < 3; ++a)
+        if (a != major && (p[a] > n - 1 || p[a] < -(n - 1))) out = a;
+    p[major] = p[major] > 0 ? n - 1 : -(n - 1);
+    const int pos = p[out] > 0;
+    p[out] = pos ? n : -n;
+    int S2, T2;
+    *nf = 2 * out + (pos ? 0 : 1);
+    switch (*nf) {
+        case 0: S2 = -p[2]; T2 = -p[1]; break;
+        case 1: S2 = p[2];  T2 = -p[1]; break;
+        case 2: S2 = p[0];  T2 = p[2];  break;
+        case 3: S2 = p[0];  T2 = -p[2]; break;
+        case 4: S2 = p[0];  T2 = -p[1]; break;
+        default: S2 = -p[0]; T2 = -p[1]; break;
+    }
+    *ni = (S2 + n - 1) / 2;
+    *nj = (T2 + n - 1) / 2;
+}
+
+/* One bilinear tap of a seamless cube lookup.  Beyond a CORNER (both coordinates outside) no face
+ * holds the texel; Vulkan ("Cube Map Corner Handling") says it should be the average of the three
+ * texels that meet at the corner and must equal their common value when they agree: formed here as
+ * a + ((b - a) + (c - a)) / 3 with a = this face's corner texel, b / c = the corner texels of the
+ * faces across the u / v edge. */
+static v3 cube_tap(const rt_oracle_face faces[6], int face, int i, int j, int n) {
+    const int oi = i < 0 || i >= n, oj = j < 0 || j >= n;
+    if (!oi && !oj) return texel_at(&faces[face], i, j);
+    const int ci = i < 0 ? 0 : (i >= n ? n - 1 : i), cj = j < 0 ? 0 : (j >= n ? n - 1 : j);
+    int f2, i2, j2;
+    if (oi && oj) {
+        const v3 a = texel_at(&faces[face], ci, cj);
+        cube_fold(face, i, cj, n, &f2, &i2, &j2);
+        const v3 b = texel_at(&faces[f2], i2, j2);
+        cube_fold(face, ci, j, n, &f2, &i2, &j2);
+        const v3 c = texel_at(&faces[f2], i2, j2);
+        return add(a, divs(add(sub(b, a), sub(c, a)), 3.0f));
+    }
+    cube_fold(face, i, j, n, &f2, &i2, &j2);
+    return texel_at(&faces[f2], i2, j2);
+}
 
 static v3 cube_sample(const rt_oracle_face faces[6], v3 r) {
     float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
@@ -174,8 +252,15 @@ static v3 cube_sample(const rt_oracle_face faces[6], v3 r) {
     float fu = floorf(u), fv = floorf(v);
     float wu = u - fu, wv = v - fv;
     int x0 = (int)fu, y0 = (int)fv;
-    v3 c00 = texel(f, x0, y0), c10 = texel(f, x0 + 1, y0);
-    v3 c01 = texel(f, x0, y0 + 1), c11 = texel(f, x0 + 1, y0 + 1);
+    v3 c00, c10, c01, c11;
+    if (cube_is_seamless(faces) && x0 >= -1 && x0 < (int)f->w && y0 >= -1 && y0 < (int)f->w) {
+        const int n = (int)f->w;
+        c00 = cube_tap(faces, face, x0, y0, n);     c10 = cube_tap(faces, face, x0 + 1, y0, n);
+        c01 = cube_tap(faces, face, x0, y0 + 1, n); c11 = cube_tap(faces, face, x0 + 1, y0 + 1, n);
+    } else {   /* not a WebGPU cube (or a NaN direction): stay inside the selected image */
+        c00 = texel(f, x0, y0);     c10 = texel(f, x0 + 1, y0);
+        c01 = texel(f, x0, y0 + 1); c11 = texel(f, x0 + 1, y0 + 1);
+    }
     return lerp3(lerp3(c00, c10, wu), lerp3(c01, c11, wu), wv);
 }
 

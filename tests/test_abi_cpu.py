@@ -79,3 +79,44 @@ def test_tile_arithmetic_matches_host(H, world):
     assert lib.rt_padded_tiles(H, world) == tiles.padded_tiles(H, world) == max(
         tiles.tiles_of_rank(H, r, world) for r in range(world))
     assert lib.rt_tiles_of_rank(H, world, world) == 0 and lib.rt_padded_tiles(H, 0) == 0
+
+
+def _plan(records, params):
+    import numpy as np
+    lib = abi.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    ok, sgn = ctypes.c_int(-1), ctypes.c_int(-1)
+    r = np.ascontiguousarray(records, dtype=np.float32)
+    abi.check(lib.rt_filter_plan(r.ctypes.data_as(fp), r.shape[0], params.ctypes.data_as(fp),
+                                 ctypes.byref(ok), ctypes.byref(sgn)))
+    return ok.value, sgn.value
+
+
+def test_filter_plan_nan_and_inf_are_sticky_wherever_the_record_sits():
+    """`if (!(len <= bound)) bound = len` let the sphere after a NaN record replace the
+    NaN bound.  Any NaN / inf record -- first, middle or last -- must switch the filter forms off."""
+    import numpy as np
+    scene = rt.synthetic_scene(12, 5)
+    p = scene.pack_params(4)
+    base = scene.pack_spheres()
+    assert _plan(base, p) == (1, 1)
+    for bad in (np.nan, np.inf, -np.inf):
+        for pos in (0, 5, 11):
+            for field in (0, 1, 2, 7):
+                s = base.copy()
+                s[pos, field] = bad
+                assert _plan(s, p) == (0, 0), (bad, pos, field)
+    # [far sphere, NaN sphere, small spheres]: the far sphere's bound must not be forgotten either
+    s = base.copy()
+    s[0, 0] = 3.0e6
+    s[1, 2] = np.nan
+    assert _plan(s, p) == (0, 0)
+    s[1, 2] = 0.0
+    assert _plan(s, p) == (0, 0)                    # reach >= 2^20
+    s[0, 0] = 400.0
+    assert _plan(s, p) == (1, 0)                    # 342 <= reach < 2^20: unsigned filter only
+    q = p.copy(); q[0] = np.nan
+    assert _plan(base, q) == (0, 0)                 # NaN camera
+    q = p.copy(); q[17] = np.inf
+    assert _plan(base, q) == (0, 0)                 # light at infinity
+    assert _plan(base[:0], p) == (1, 1)             # empty scene

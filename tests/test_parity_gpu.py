@@ -303,3 +303,81 @@ def test_two_contexts_side_by_side(oracle):
         assert ra.stats()["frames"] == 2 and rb.stats()["frames"] == 1
     finally:
         ra.close(); rb.close()
+
+
+@pytest.mark.parametrize("n", [40, 300])
+def test_nan_and_inf_records_in_the_middle_of_the_scene(oracle, n):
+    """a NaN / inf sphere record that is NOT the last one used to drop out of the scene
+    bound, so fast mode kept its filter and hierarchy outside their proven range.  Now any such record
+    sends the frame to the literal kernel: fast == strict == oracle."""
+    scene = rt.synthetic_scene(n, 600 + n)
+    s = scene.pack_spheres().copy()
+    s[1, 0] = 3.0e6                  # far sphere first ...
+    s[n // 3, 2] = np.nan            # ... a NaN record in the middle ...
+    s[n // 2, 7] = np.inf            # ... an infinite radius, then ordinary spheres
+    s[n // 2 + 1, 1] = -np.inf
+    p = scene.pack_params(4)
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    W, H = 160, 96
+    ref, _, rays = oracle.render(p, s, sky.faces, W, H)
+    L = abi.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    for strict in (True, False):
+        ctx = ctypes.c_void_p()
+        abi.check(L.rt_create(0, ctypes.byref(ctx)))
+        try:
+            abi.check(L.rt_resize(ctx, W, H), ctx)
+            abi.check(L.rt_set_mode(ctx, 1 if strict else 0), ctx)
+            abi.check(L.rt_write_params(ctx, p.ctypes.data_as(fp)), ctx)
+            abi.check(L.rt_write_spheres(ctx, s.ctypes.data_as(fp), n), ctx)
+            for f in range(6):
+                face = np.ascontiguousarray(sky.faces[f])
+                abi.check(L.rt_write_cubemap_face(ctx, f, face.shape[1], face.shape[0], face.ctypes.data), ctx)
+            abi.check(L.rt_render(ctx), ctx)
+            img = np.zeros((H, W, 4), np.uint8)
+            abi.check(L.rt_read_pixels(ctx, img.ctypes.data, img.nbytes), ctx)
+            st = abi.RtStats()
+            abi.check(L.rt_get_stats(ctx, ctypes.byref(st)), ctx)
+        finally:
+            L.rt_destroy(ctx)
+        assert np.array_equal(img, ref), (strict, diff_stats(img, ref))
+        assert st.rays == rays
+
+
+# ---- C4: the headline frame row-tiled over 2 / 4 / 8 ranks ------------------------------------------
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c4_emulated_ranks_reassemble_the_golden_c3_frame(world):
+    """BASELINE config C4 = the C3 frame (3840x2160, 1024 spheres, 8 bounces) split into 8-row tiles,
+    tile t rendered by rank t % world.  One GPU plays every rank in turn (rt_set_partition +
+    rt_render_to into that rank's slot of the all-gather layout), rt_assemble_frame de-interleaves:
+    the frame must hash to the ORACLE's C3 frame (tests/golden/frames.json) and the ranks' ray
+    counts must add up to the oracle's."""
+    import torch
+    fr = json.load(open(os.path.join(G, "frames.json")))["C3"]
+    cfg, scene = config_inputs("C3")
+    W, H, B = cfg["width"], cfg["height"], cfg["bounces"]
+    assert (W, H, len(scene.spheres), B) == (3840, 2160, 1024, 8)
+    msg = tiles.message_bytes(W, H, world)
+    gathered = torch.zeros(world * msg, dtype=torch.uint8, device="cuda")
+    frame = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ren = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize()
+    L = abi.load()
+    rays = 0
+    try:
+        for r in range(world):
+            abi.check(L.rt_set_partition(ren._ctx, r, world), ren._ctx)
+            ren.rank, ren.world = r, world
+            part = gathered[r * msg:(r + 1) * msg]
+            ren.render_to(part.data_ptr(), part.numel(), stream)
+            ren.wait()
+            st = ren.stats()
+            assert st["local_tiles"] == tiles.tiles_of_rank(H, r, world)
+            rays += st["rays"]
+        ren.assemble_frame(gathered.data_ptr(), frame.data_ptr(), world, stream)
+        torch.cuda.synchronize()
+    finally:
+        ren.close()
+    got = frame.cpu().numpy()
+    assert hashlib.sha256(got.tobytes()).hexdigest() == fr["sha256"]
+    assert rays == fr["rays"]
