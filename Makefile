@@ -4,7 +4,7 @@ ARCH     ?= gfx950
 CSRC     := compute_raytracer_amd/csrc
 LIB      := compute_raytracer_amd/librt355.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-fast-math -Wall -Wno-unused-function $(EXTRA)
-OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_bvh.o $(CSRC)/rt_triangles.o $(CSRC)/rt_assemble.o
+OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_bvh.o $(CSRC)/rt_triangles.o $(CSRC)/rt_assemble.o $(CSRC)/rt_comm.o
 
 all: lib oracle node
 
@@ -24,11 +24,15 @@ $(CSRC)/rt_triangles.o: $(CSRC)/rt_triangles.hip $(CSRC)/rt_device.h $(CSRC)/rt_
 $(CSRC)/rt_assemble.o: $(CSRC)/rt_assemble.hip $(CSRC)/rt_types.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/rt_api.o: $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h include/rt355.h
+$(CSRC)/rt_api.o: $(CSRC)/rt_api.hip $(CSRC)/rt_ctx.h $(CSRC)/rt_bvh_build.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h include/rt355.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
 
+# the RCCL entry points (rt_comm_init / rt_render_gather / rt_group_*)
+$(CSRC)/rt_comm.o: $(CSRC)/rt_comm.hip $(CSRC)/rt_ctx.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h include/rt355.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(LIB): $(OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -L/opt/rocm/lib -lrccl
 
 oracle:
 	$(MAKE) -s -C oracle

@@ -14,6 +14,8 @@ RT_ERR_HIP = -3
 RT_ERR_UNSUPPORTED = -4
 RT_ERR_STATE = -5
 RT_ERR_CAPACITY = -6
+RT_ERR_COMM = -7
+RT355_COMM_ID_BYTES = 128
 
 RT_KERNEL_RAYTRACER = 0
 RT_KERNEL_HEATMAP = 1
@@ -28,6 +30,8 @@ SYMBOLS = [
     "rt_set_variant", "rt_set_partition", "rt_tiles_of_rank", "rt_padded_tiles", "rt_render", "rt_wait",
     "rt_read_pixels", "rt_get_stats", "rt_render_to", "rt_assemble_frame", "rt_device_pixels",
     "rt_build_hierarchy", "rt_filter_plan",
+    "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_render_gather", "rt_frame_pixels", "rt_read_frame",
+    "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_ctx", "rt_group_render", "rt_group_wait",
 ]
 
 
@@ -37,6 +41,7 @@ class RtStats(ctypes.Structure):
         ("spheres", ctypes.c_uint32), ("rays", ctypes.c_uint64), ("kernel_ms", ctypes.c_float),
         ("prep_ms", ctypes.c_float), ("frames", ctypes.c_uint32), ("mode", ctypes.c_int),
         ("batch_frames", ctypes.c_uint32), ("batch_kernel_ms", ctypes.c_float),
+        ("gather_ms", ctypes.c_float), ("batch_gather_ms", ctypes.c_float),
     ]
 
 
@@ -114,6 +119,18 @@ def load():
         "rt_device_pixels": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "rt_build_hierarchy": (ctypes.c_int, [fp, u32, fp, ctypes.POINTER(u32), u32, ctypes.POINTER(u32)]),
         "rt_filter_plan": (ctypes.c_int, [fp, u32, fp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+        "rt_comm_unique_id": (ctypes.c_int, [vp]),
+        "rt_comm_init": (ctypes.c_int, [vp, vp, u32, u32]),
+        "rt_comm_destroy": (ctypes.c_int, [vp]),
+        "rt_render_gather": (ctypes.c_int, [vp, ctypes.c_int]),
+        "rt_frame_pixels": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]),
+        "rt_read_frame": (ctypes.c_int, [vp, vp, sz]),
+        "rt_group_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp)]),
+        "rt_group_destroy": (ctypes.c_int, [vp]),
+        "rt_group_size": (ctypes.c_int, [vp]),
+        "rt_group_ctx": (vp, [vp, ctypes.c_int]),
+        "rt_group_render": (ctypes.c_int, [vp, ctypes.c_int]),
+        "rt_group_wait": (ctypes.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

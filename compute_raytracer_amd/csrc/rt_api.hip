@@ -2,9 +2,7 @@
 // One context = one GPU + four streams (frames in flight); see the header for what each entry point replaces in
 // the reference's renderer-raytracing.ts.  No CPU fallback: without a gfx950 device
 // rt_create fails and nothing else can be called.
-#include "../../include/rt355.h"
-#include "rt_types.h"
-#include "rt_tri_types.h"
+#include "rt_ctx.h"
 
 #include <algorithm>
 #include <cmath>
@@ -16,25 +14,9 @@
 
 #include "rt_bvh_build.h"
 
+thread_local std::string g_rt_err;
+
 namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const char* what) {
-    g_err = what;
-    return code;
-}
-int fail_hip(hipError_t e, const char* where) {
-    char buf[256];
-    std::snprintf(buf, sizeof buf, "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
-    g_err = buf;
-    return RT_ERR_HIP;
-}
-#define RT_HIP(call)                                                   \
-    do {                                                               \
-        hipError_t e_ = (call);                                        \
-        if (e_ != hipSuccess) return fail_hip(e_, #call);              \
-    } while (0)
 
 uint32_t tiles_total(uint32_t H) { return (H + 7u) / 8u; }
 
@@ -72,74 +54,11 @@ void rt_plan(double scene_bound, const float* p, bool& filter_ok, uint32_t& sign
 
 }  // namespace
 
-// Frames the library itself keeps concurrent (rt_render rotates over this many streams and colour
-// buffers).  Why: at the end of a frame every lane of the persistent hierarchy kernel still carries
-// a path of up to 2*bounces dependent rays; that tail is latency, not work (0.45 ms of a 2.9 ms C3
-// frame, 0.45 of 0.8 ms when 8 ranks share the frame).  Frames in flight each take a share of the
-// chip (RtFrameArgs::grid_share), so one frame's tail runs beside the others' bulk.
-constexpr int kStreams = 4;
-constexpr size_t kCounterBytes = (size_t)RT_RAY_COUNTERS * RT_RAY_COUNTER_STRIDE;   // partial ray counters of one frame
-constexpr size_t kCtrlBytes = kCounterBytes + 32u;                                   // + the 32-byte control block
-
-struct rt_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;        // uploads, read-back, and frames 0, 3, 6 ... of rt_render (= streams[0])
-    hipStream_t streams[kStreams] = {nullptr};   // rt_render rotates: consecutive frames may overlap on the device
-    hipEvent_t ev_prep0[RT355_MAX_IN_FLIGHT] = {nullptr}, ev_k0[RT355_MAX_IN_FLIGHT] = {nullptr},
-               ev_k1[RT355_MAX_IN_FLIGHT] = {nullptr};
-    hipEvent_t ev_scene = nullptr;       // the scene arrays / hierarchy a frame reads are complete ...
-    hipStream_t scene_stream = nullptr;  // ... recorded on this stream
-    uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
-    hipStream_t slot_stream[RT355_MAX_IN_FLIGHT] = {nullptr};   // the stream each of them was enqueued on
-    uint32_t frames_rendered = 0;        // rt_render calls: parity selects stream and colour buffer
-    uint32_t W = 0, H = 0;
-    uint32_t rank = 0, world = 1;
-    float params[24] = {0};
-    bool have_params = false;
-    bool prep_spheres_valid = false;     // prep_spheres ran since the last rt_write_spheres
-    bool prep_params_valid = false;      // ... and since the last rt_write_params (camera / light records)
-    float* d_records = nullptr;
-    uint32_t n = 0, cap_n = 0;
-    bool have_spheres = false;
-    float4* d_scene = nullptr;           // 8 float4 arrays of n16: geo lgt cam col geo_f lgt_f cam_f + {geo_w,lgt_w,cam_w,-}
-    uint32_t n16 = 0;                    // n rounded up to a multiple of 16
-    float scene_bound = 0.0f;            // max over spheres of |center| + radius (host side)
-    // bounding-sphere hierarchy (rt_bvh.hip): host copy of the records it is built from, the
-    // build result and its device copy
-    std::vector<float> h_records;
-    std::vector<float> h_bvh_rec;
-    std::vector<uint32_t> h_bvh_link;
-    float4* d_bvh_rec = nullptr;
-    uint32_t* d_bvh_link = nullptr;
-    uint32_t bvh_cap = 0, bvh_nodes = 0;
-    bool bvh_valid = false;              // built for the current spheres
-    uint8_t* d_face[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
-    uint8_t* d_out = nullptr;              // colour buffer of the LATEST rt_render (one of d_outs)
-    uint8_t* d_outs[kStreams] = {nullptr};
-    size_t out_bytes = 0;
-    // per frame in flight: RT_RAY_COUNTERS partial ray counters (kCtrlBytes - 32 bytes), then a 32-byte
-    // control block: unused u64, queue count, queue head, pixel / tile-pair cursor
-    unsigned long long* d_rays = nullptr;
-    float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
-    size_t queue_cap = 0;                  // entries
-    unsigned long long* h_rays = nullptr;  // pinned copy of the latest frame's partial counters
-    // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
-    struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };
-    DevBuf d_tri, d_nodes, d_blas, d_tri_lookup, d_blas_lookup, d_tex;
-    uint32_t tex_w = 0, tex_h = 0;
-    int scene_kind = 0;                    // 0 spheres, 1 triangles: the primitive type written last
-    int mode = RT_MODE_FAST;
-    int variant = 0;
-    int kernel = RT_KERNEL_RAYTRACER;
-    rt_stats stats = {};
-};
-
 extern "C" {
 
 int rt_abi_version(void) { return RT355_ABI_VERSION; }
 
-const char* rt_last_error(rt_ctx*) { return g_err.c_str(); }
+const char* rt_last_error(rt_ctx*) { return g_rt_err.c_str(); }
 
 int rt_create(int device, rt_ctx** out) {
     if (!out) return fail(RT_ERR_INVALID_ARG, "rt_create: out is NULL");
@@ -192,6 +111,7 @@ int rt_destroy(rt_ctx* c) {
     for (uint32_t i = 0; i < c->in_flight; ++i) (void)hipEventSynchronize(c->ev_k1[i]);
     for (int k = 0; k < kStreams; ++k)
         if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
+    rt_comm_release(c);
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_scene);
     for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
@@ -216,7 +136,8 @@ int rt_destroy(rt_ctx* c) {
 }
 
 int rt_wait(rt_ctx* c);
-static uint32_t local_tiles(const rt_ctx* c) { return rt_tiles_of_rank(c->H, c->rank, c->world); }
+uint32_t rt_local_tiles(const rt_ctx* c) { return rt_tiles_of_rank(c->H, c->rank, c->world); }
+static uint32_t local_tiles(const rt_ctx* c) { return rt_local_tiles(c); }
 
 uint32_t rt_tiles_of_rank(uint32_t height, uint32_t rank, uint32_t world) {
     if (world == 0 || rank >= world) return 0;
@@ -230,7 +151,8 @@ uint32_t rt_padded_tiles(uint32_t height, uint32_t world) {
 }
 
 // Scene-setup calls change device state that frames in flight may read: they drain first.
-static int drain(rt_ctx* c) { return c->in_flight ? rt_wait(c) : RT_OK; }
+int rt_drain(rt_ctx* c) { return c->in_flight ? rt_wait(c) : RT_OK; }
+static int drain(rt_ctx* c) { return rt_drain(c); }
 
 static int ensure_out(rt_ctx* c) {
     // sized for the padded tile count so that the buffer can be an all-gather operand; one
@@ -287,6 +209,8 @@ int rt_resize(rt_ctx* c, uint32_t width, uint32_t height) {
 int rt_set_partition(rt_ctx* c, uint32_t rank, uint32_t world) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_set_partition: ctx is NULL");
     if (world == 0 || rank >= world) return fail(RT_ERR_INVALID_ARG, "rt_set_partition: need rank < world");
+    if (c->comm && (rank != c->rank || world != c->world))
+        return fail(RT_ERR_STATE, "rt_set_partition: the partition of a context with a communicator is its rank in the group");
     RT_HIP(hipSetDevice(c->device));
     { int rc = drain(c); if (rc != RT_OK) return rc; }
     c->rank = rank;
@@ -352,6 +276,7 @@ int rt_write_cubemap_face(rt_ctx* c, int face, uint32_t w, uint32_t h, const uin
     }
     RT_HIP(hipMemcpyAsync(c->d_face[face], rgba, bytes, hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
+    c->face_texel0[face] = (uint32_t)rgba[0] | ((uint32_t)rgba[1] << 8) | ((uint32_t)rgba[2] << 16);
     return RT_OK;
 }
 
@@ -441,7 +366,7 @@ int rt_set_variant(rt_ctx* c, int variant) {
     return RT_OK;
 }
 
-static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
+int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     if (!c->W || !c->H) return fail(RT_ERR_STATE, "rt_render: rt_resize has not been called");
     if (!c->have_params) return fail(RT_ERR_STATE, "rt_render: rt_write_params has not been called");
     const bool tri = c->scene_kind == 1;
@@ -575,6 +500,12 @@ static int enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     unsigned long long* counters = c->d_rays + (kCtrlBytes / 8u) * slot;
     unsigned long long* ctrl = counters + kCounterBytes / 8u;
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
+    fa.sky_flat = 1u;       // six 1x1 faces of one colour
+    fa.sky_seamless = 1u;   // six equal squares: what WebGPU accepts as a cube texture (CM:35-79: 512 x 512 x 6)
+    for (int i = 0; i < 6; ++i) {
+        if (c->fw[i] != 1u || c->fh[i] != 1u || c->face_texel0[i] != c->face_texel0[0]) fa.sky_flat = 0u;
+        if (c->fw[i] != c->fw[0] || c->fh[i] != c->fw[0]) fa.sky_seamless = 0u;
+    }
     fa.out = dst;
     fa.rays = counters;
     fa.queue = queue_pipeline ? c->d_queue : nullptr;   // rt_kernels.hip takes the pipeline only with a queue
@@ -615,7 +546,7 @@ int rt_render(rt_ctx* c) {
     // back to back overlap on the device; rt_read_pixels returns the latest one
     const uint32_t k = c->frames_rendered % (uint32_t)kStreams;
     uint8_t* dst = c->d_outs[k];
-    int rc = enqueue(c, dst, c->streams[k]);
+    int rc = rt_enqueue(c, dst, c->streams[k]);
     if (rc == RT_OK) { c->d_out = dst; ++c->frames_rendered; }
     return rc;
 }
@@ -625,7 +556,7 @@ int rt_render_to(rt_ctx* c, void* device_dst, size_t cap, void* hip_stream) {
     const size_t need = (size_t)local_tiles(c) * 8u * c->W * 4u;
     if (cap < need) return fail(RT_ERR_CAPACITY, "rt_render_to: destination smaller than local_tiles*8*W*4");
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    return enqueue(c, static_cast<uint8_t*>(device_dst), s);
+    return rt_enqueue(c, static_cast<uint8_t*>(device_dst), s);
 }
 
 int rt_wait(rt_ctx* c) {
@@ -653,6 +584,7 @@ int rt_wait(rt_ctx* c) {
         }
         (void)hipGetLastError();
         c->in_flight = 0;
+        return rt_comm_after_wait(c);
     }
     return RT_OK;
 }

@@ -205,7 +205,8 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
 // 8-wave workgroups are held to 80 VGPRs (6 waves per SIMD, three workgroups per CU): the walk is a
 // chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
 // workgroups serve scenes whose nodes leave room for one workgroup per CU only (4 waves per SIMD).
-template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
+// FLAT: compiled for a one-colour 1x1 sky (A.sky_flat; C1-C4) -- no cube filtering code in the kernel.
+template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
@@ -230,8 +231,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     __syncthreads();
 
     const Scene sc = unpack_scene(A);
-    bool flat_sky = true;
-    for (int f = 0; f < 6; ++f) flat_sky = flat_sky && A.fw[f] == 1u && A.fh[f] == 1u;
     const uint32_t tiles_x = (A.W + 7u) / 8u;
     const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
     uint32_t cur = 0, end = 0;                                   // wave-uniform chunk cursor
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
                     opix = (ty * 8u + row) * A.W + x;
                     ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
-                    if (sc.bounces == 0u) fog = scale(sc.minIntensity, cube_sample(A, rd, lut, flat_sky));   // no ray will be cast
+                    if (sc.bounces == 0u) fog = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 2>(A, rd, lut));   // no ray will be cast
                     color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
                     affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
                     shadow = false;
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 // One sky sample serves RK:124 (the ray missed) and RK:93-96 (the fog colour of
                 // the pixel = the sky along the PRIMARY direction, which is rd at bounce 0).
                 v3 sky = V(0, 0, 0);
-                if (bounce == 0u || idx < 0) sky = scale(sc.minIntensity, cube_sample(A, rd, lut, flat_sky));
+                if (bounce == 0u || idx < 0) sky = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 2>(A, rd, lut));
                 if (bounce == 0u) fog = sky;
                 if (idx < 0) {                                           // RK:122-126
                     color = divs(add(scale(sum, color), scale(affect, sky)), next);
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
 
 template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
 hipError_t launch_bvh_as(const RtFrameArgs& a, size_t lds, hipStream_t s) {
-    auto k = bvh_pixels<WAVES, SGN, NLDS, CAP, TAIL>;
+    auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, TAIL, true> : bvh_pixels<WAVES, SGN, NLDS, CAP, TAIL, false>;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

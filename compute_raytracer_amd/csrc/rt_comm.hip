@@ -1,0 +1,355 @@
+// rt_comm.hip -- multi-GPU behind the C ABI: the frame is split into 8-row tiles over the GPUs of one
+// node (tile t -> rank t % world), each GPU renders its tiles, and the library itself moves them over
+// RCCL (xGMI) and de-interleaves them into the row-major frame.  One call -- rt_render_gather, or
+// rt_group_render for a single-process host -- is the whole of RendererRaytracing.render()'s GPU work
+// (RR:434-470) across the group.  SURVEY.md 8(b)/(e).
+//
+// Two ways to form the group:
+//   * one process per GPU (torchrun, MPI, ...): rank 0 calls rt_comm_unique_id, the host hands the
+//     128 bytes to the other ranks by any side channel, every rank calls rt_comm_init on its context;
+//   * one process, all GPUs (the reference's host is ONE Node thread): rt_group_create builds a context
+//     per device and an ncclCommInitAll communicator.
+// The exchange: gather to a root (grouped ncclSend / ncclRecv: each rank's padded tile buffer
+// travels once, over its direct xGMI link to the root) or ncclAllGather in place (every rank ends up
+// with the frame).  The root renders straight into its slot of the gather buffer, so nothing is copied
+// before the exchange; `assemble_frame` (rt_assemble.hip) de-interleaves on the same stream.
+// Frames in flight rotate over the context's four streams exactly as rt_render does; RCCL orders the
+// exchanges of one communicator among themselves.
+#include "rt_ctx.h"
+
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+
+struct rt_comm_state {
+    ncclComm_t comm = nullptr;
+    bool owns_comm = true;                 // false: the communicator belongs to an rt_group
+    uint8_t* d_gather[kStreams] = {nullptr};   // [world][padded_tiles][8][W][4], on ranks that receive
+    uint8_t* d_frame[kStreams] = {nullptr};    // [H][W][4], on ranks that receive
+    size_t gather_bytes = 0, frame_bytes = 0;
+    int latest = -1;                       // buffer set of the latest rt_render_gather (-1: none yet)
+    bool latest_has_frame = false;         // this rank received that frame
+    hipEvent_t ev_r1[RT355_MAX_IN_FLIGHT] = {nullptr};   // end of the render, before the exchange
+    bool slot_gathered[RT355_MAX_IN_FLIGHT] = {false};
+};
+
+static int fail_nccl(ncclResult_t r, const char* where) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s: %s (%d)", where, ncclGetErrorString(r), (int)r);
+    g_rt_err = buf;
+    return RT_ERR_COMM;
+}
+#define RT_NCCL(call)                                                  \
+    do {                                                               \
+        ncclResult_t r_ = (call);                                      \
+        if (r_ != ncclSuccess) return fail_nccl(r_, #call);            \
+    } while (0)
+
+static size_t message_bytes(const rt_ctx* c) { return (size_t)rt_padded_tiles(c->H, c->world) * 8u * c->W * 4u; }
+
+static void free_buffers(rt_comm_state* s) {
+    for (int k = 0; k < kStreams; ++k) {
+        (void)hipFree(s->d_gather[k]); s->d_gather[k] = nullptr;
+        (void)hipFree(s->d_frame[k]); s->d_frame[k] = nullptr;
+    }
+    s->gather_bytes = s->frame_bytes = 0;
+    s->latest = -1;
+    s->latest_has_frame = false;
+}
+
+void rt_comm_release(rt_ctx* c) {
+    rt_comm_state* s = c->comm;
+    if (!s) return;
+    free_buffers(s);
+    for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i)
+        if (s->ev_r1[i]) (void)hipEventDestroy(s->ev_r1[i]);
+    if (s->comm && s->owns_comm) (void)ncclCommDestroy(s->comm);
+    delete s;
+    c->comm = nullptr;
+}
+
+// render time and exchange time of the frames the last rt_wait completed
+int rt_comm_after_wait(rt_ctx* c) {
+    rt_comm_state* s = c->comm;
+    c->stats.gather_ms = 0.0f;
+    c->stats.batch_gather_ms = 0.0f;
+    if (!s) return RT_OK;
+    float kernel_sum = 0.0f;
+    bool any = false;
+    for (uint32_t i = 0; i < c->stats.batch_frames && i < RT355_MAX_IN_FLIGHT; ++i) {
+        if (!s->slot_gathered[i]) continue;
+        float render = 0.0f, gather = 0.0f;
+        if (hipEventElapsedTime(&render, c->ev_k0[i], s->ev_r1[i]) == hipSuccess &&
+            hipEventElapsedTime(&gather, s->ev_r1[i], c->ev_k1[i]) == hipSuccess) {
+            c->stats.kernel_ms = render;
+            c->stats.gather_ms = gather;
+            c->stats.batch_gather_ms += gather;
+            kernel_sum += render;
+            any = true;
+        }
+        s->slot_gathered[i] = false;
+    }
+    if (any) c->stats.batch_kernel_ms = kernel_sum;
+    (void)hipGetLastError();
+    return RT_OK;
+}
+
+static int attach(rt_ctx* c, ncclComm_t comm, bool owns, uint32_t rank, uint32_t world) {
+    rt_comm_state* s = new (std::nothrow) rt_comm_state();
+    if (!s) return fail(RT_ERR_HIP, "rt_comm_init: out of host memory");
+    s->comm = comm;
+    s->owns_comm = owns;
+    for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) {
+        hipError_t e = hipEventCreate(&s->ev_r1[i]);
+        if (e != hipSuccess) {
+            c->comm = s;
+            rt_comm_release(c);
+            return fail_hip(e, "rt_comm_init: hipEventCreate");
+        }
+    }
+    int rc = rt_set_partition(c, rank, world);     // before the communicator is attached: afterwards the partition is fixed
+    c->comm = s;
+    if (rc != RT_OK) rt_comm_release(c);
+    return rc;
+}
+
+// buffers of the ranks that receive: sized for the current target and partition
+static int ensure_buffers(rt_ctx* c, bool receives) {
+    rt_comm_state* s = c->comm;
+    if (!receives) return RT_OK;
+    const size_t gb = message_bytes(c) * c->world, fb = (size_t)c->H * c->W * 4u;
+    if (gb <= s->gather_bytes && fb <= s->frame_bytes && s->d_gather[0] && s->d_frame[0]) return RT_OK;
+    { int rc = rt_drain(c); if (rc != RT_OK) return rc; }
+    free_buffers(s);
+    for (int k = 0; k < kStreams; ++k) {
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_gather[k]), gb));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_frame[k]), fb));
+        RT_HIP(hipMemsetAsync(s->d_gather[k], 0, gb, c->stream));
+    }
+    RT_HIP(hipStreamSynchronize(c->stream));
+    s->gather_bytes = gb;
+    s->frame_bytes = fb;
+    return RT_OK;
+}
+
+// The render of one frame and, on the same stream, its exchange and de-interleave.  The NCCL calls
+// are issued WITHOUT group markers: the callers bracket them (one context: its own group; an
+// rt_group: one group over all its devices, as a single thread driving several GPUs must).
+static int render_part(rt_ctx* c, int root, uint32_t k, uint8_t** part) {
+    rt_comm_state* s = c->comm;
+    const bool receives = root < 0 || (uint32_t)root == c->rank;
+    { int rc = ensure_buffers(c, receives); if (rc != RT_OK) return rc; }
+    const size_t msg = message_bytes(c);
+    *part = receives ? s->d_gather[k] + msg * c->rank : c->d_outs[k];
+    if (!*part) return fail(RT_ERR_STATE, "rt_render_gather: rt_resize has not been called");
+    int rc = rt_enqueue(c, *part, c->streams[k]);
+    if (rc != RT_OK) return rc;
+    const uint32_t slot = c->in_flight - 1u;
+    RT_HIP(hipEventRecord(s->ev_r1[slot], c->streams[k]));
+    s->slot_gathered[slot] = true;
+    return RT_OK;
+}
+
+static int exchange_part(rt_ctx* c, int root, uint32_t k, uint8_t* part) {
+    rt_comm_state* s = c->comm;
+    const size_t msg = message_bytes(c);
+    hipStream_t st = c->streams[k];
+    if (root < 0) {
+        RT_NCCL(ncclAllGather(part, s->d_gather[k], msg, ncclUint8, s->comm, st));     // in place: part = recv + rank * msg
+    } else if ((uint32_t)root == c->rank) {
+        for (uint32_t r = 0; r < c->world; ++r)
+            if (r != c->rank) RT_NCCL(ncclRecv(s->d_gather[k] + msg * r, msg, ncclUint8, (int)r, s->comm, st));
+    } else {
+        RT_NCCL(ncclSend(part, msg, ncclUint8, root, s->comm, st));
+    }
+    return RT_OK;
+}
+
+static int finish_part(rt_ctx* c, int root, uint32_t k, uint8_t* part) {
+    rt_comm_state* s = c->comm;
+    const bool receives = root < 0 || (uint32_t)root == c->rank;
+    hipStream_t st = c->streams[k];
+    if (receives)
+        RT_HIP(rt_launch_assemble(s->d_gather[k], s->d_frame[k], c->W, c->H, c->world, rt_padded_tiles(c->H, c->world), st));
+    // the frame is complete when the exchange and the de-interleave are: move the slot's end event
+    RT_HIP(hipEventRecord(c->ev_k1[c->in_flight - 1u], st));
+    s->latest = (int)k;
+    s->latest_has_frame = receives;
+    c->d_out = part;       // rt_read_pixels / rt_device_pixels keep returning THIS rank's tiles
+    ++c->frames_rendered;
+    return RT_OK;
+}
+
+static int check_gather_args(rt_ctx* c, int root, const char* who) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, who);
+    if (!c->comm) return fail(RT_ERR_STATE, "rt_render_gather: no communicator (rt_comm_init / rt_group_create first)");
+    if (root < -1 || root >= (int)c->world) return fail(RT_ERR_INVALID_ARG, "rt_render_gather: root must be -1 (all ranks) or a rank");
+    if (!c->W || !c->H) return fail(RT_ERR_STATE, "rt_render_gather: rt_resize has not been called");
+    return RT_OK;
+}
+
+struct rt_group {
+    std::vector<rt_ctx*> ctx;
+    std::vector<ncclComm_t> comms;
+};
+
+extern "C" {
+
+int rt_comm_unique_id(uint8_t id[RT355_COMM_ID_BYTES]) {
+    if (!id) return fail(RT_ERR_INVALID_ARG, "rt_comm_unique_id: id is NULL");
+    static_assert(RT355_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "RT355_COMM_ID_BYTES must be RCCL's NCCL_UNIQUE_ID_BYTES");
+    ncclUniqueId u;
+    RT_NCCL(ncclGetUniqueId(&u));
+    std::memcpy(id, u.internal, RT355_COMM_ID_BYTES);
+    return RT_OK;
+}
+
+int rt_comm_init(rt_ctx* c, const uint8_t id[RT355_COMM_ID_BYTES], uint32_t rank, uint32_t world) {
+    if (!c || !id) return fail(RT_ERR_INVALID_ARG, "rt_comm_init: NULL argument");
+    if (world == 0 || rank >= world) return fail(RT_ERR_INVALID_ARG, "rt_comm_init: need rank < world");
+    if (c->comm) return fail(RT_ERR_STATE, "rt_comm_init: the context already has a communicator");
+    RT_HIP(hipSetDevice(c->device));
+    { int rc = rt_drain(c); if (rc != RT_OK) return rc; }
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, RT355_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    RT_NCCL(ncclCommInitRank(&comm, (int)world, u, (int)rank));
+    int rc = attach(c, comm, true, rank, world);
+    if (rc != RT_OK && !c->comm) (void)ncclCommDestroy(comm);
+    return rc;
+}
+
+int rt_comm_destroy(rt_ctx* c) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_comm_destroy: ctx is NULL");
+    if (!c->comm) return RT_OK;
+    if (!c->comm->owns_comm) return fail(RT_ERR_STATE, "rt_comm_destroy: the communicator belongs to an rt_group");
+    RT_HIP(hipSetDevice(c->device));
+    { int rc = rt_drain(c); if (rc != RT_OK) return rc; }
+    c->d_out = c->d_outs[0];
+    c->out_bytes = c->d_outs[0] ? c->out_bytes : 0;
+    rt_comm_release(c);
+    return rt_set_partition(c, 0, 1);
+}
+
+int rt_render_gather(rt_ctx* c, int root) {
+    { int rc = check_gather_args(c, root, "rt_render_gather: ctx is NULL"); if (rc != RT_OK) return rc; }
+    if (!c->comm->owns_comm) return fail(RT_ERR_STATE, "rt_render_gather: this context belongs to an rt_group; call rt_group_render");
+    RT_HIP(hipSetDevice(c->device));
+    const uint32_t k = c->frames_rendered % (uint32_t)kStreams;
+    uint8_t* part = nullptr;
+    { int rc = render_part(c, root, k, &part); if (rc != RT_OK) return rc; }
+    RT_NCCL(ncclGroupStart());
+    int rc = exchange_part(c, root, k, part);
+    ncclResult_t ge = ncclGroupEnd();
+    if (rc != RT_OK) return rc;
+    if (ge != ncclSuccess) return fail_nccl(ge, "ncclGroupEnd");
+    return finish_part(c, root, k, part);
+}
+
+int rt_frame_pixels(rt_ctx* c, void** out_ptr, size_t* out_bytes) {
+    if (!c || !out_ptr || !out_bytes) return fail(RT_ERR_INVALID_ARG, "rt_frame_pixels: NULL argument");
+    if (!c->comm || c->comm->latest < 0) return fail(RT_ERR_STATE, "rt_frame_pixels: no rt_render_gather yet");
+    if (!c->comm->latest_has_frame) return fail(RT_ERR_STATE, "rt_frame_pixels: this rank did not receive the frame (it is not the root)");
+    *out_ptr = c->comm->d_frame[c->comm->latest];
+    *out_bytes = (size_t)c->H * c->W * 4u;
+    return RT_OK;
+}
+
+int rt_read_frame(rt_ctx* c, uint8_t* dst, size_t cap) {
+    if (!c || !dst) return fail(RT_ERR_INVALID_ARG, "rt_read_frame: NULL argument");
+    void* p = nullptr;
+    size_t bytes = 0;
+    { int rc = rt_frame_pixels(c, &p, &bytes); if (rc != RT_OK) return rc; }
+    if (cap < bytes) return fail(RT_ERR_CAPACITY, "rt_read_frame: destination smaller than W*H*4");
+    { int rc = rt_wait(c); if (rc != RT_OK) return rc; }
+    RT_HIP(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// ---- one process, all GPUs -------------------------------------------------------------------------------
+
+int rt_group_create(int n_devices, rt_group** out) {
+    if (!out) return fail(RT_ERR_INVALID_ARG, "rt_group_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(RT_ERR_NO_DEVICE, "rt_group_create: no HIP device visible (this library has no CPU path)");
+    }
+    if (n_devices == 0) n_devices = count;
+    if (n_devices < 0 || n_devices > count) return fail(RT_ERR_NO_DEVICE, "rt_group_create: more devices requested than visible");
+    rt_group* g = new (std::nothrow) rt_group();
+    if (!g) return fail(RT_ERR_HIP, "rt_group_create: out of host memory");
+    for (int d = 0; d < n_devices; ++d) {
+        rt_ctx* c = nullptr;
+        int rc = rt_create(d, &c);
+        if (rc != RT_OK) { rt_group_destroy(g); return rc; }
+        g->ctx.push_back(c);
+    }
+    g->comms.assign((size_t)n_devices, nullptr);
+    std::vector<int> devs((size_t)n_devices);
+    for (int d = 0; d < n_devices; ++d) devs[(size_t)d] = d;
+    ncclResult_t r = ncclCommInitAll(g->comms.data(), n_devices, devs.data());
+    if (r != ncclSuccess) { g->comms.clear(); rt_group_destroy(g); return fail_nccl(r, "ncclCommInitAll"); }
+    for (int d = 0; d < n_devices; ++d) {
+        (void)hipSetDevice(d);
+        int rc = attach(g->ctx[(size_t)d], g->comms[(size_t)d], false, (uint32_t)d, (uint32_t)n_devices);
+        if (rc != RT_OK) { rt_group_destroy(g); return rc; }
+    }
+    *out = g;
+    return RT_OK;
+}
+
+int rt_group_destroy(rt_group* g) {
+    if (!g) return RT_OK;
+    for (rt_ctx* c : g->ctx) (void)rt_destroy(c);          // drains, releases the gather buffers
+    for (ncclComm_t comm : g->comms)
+        if (comm) (void)ncclCommDestroy(comm);
+    delete g;
+    return RT_OK;
+}
+
+int rt_group_size(const rt_group* g) { return g ? (int)g->ctx.size() : 0; }
+
+rt_ctx* rt_group_ctx(rt_group* g, int i) {
+    if (!g || i < 0 || i >= (int)g->ctx.size()) { (void)fail(RT_ERR_INVALID_ARG, "rt_group_ctx: index out of range"); return nullptr; }
+    return g->ctx[(size_t)i];
+}
+
+int rt_group_render(rt_group* g, int root) {
+    if (!g || g->ctx.empty()) return fail(RT_ERR_INVALID_ARG, "rt_group_render: group is NULL");
+    const size_t n = g->ctx.size();
+    std::vector<uint8_t*> part(n, nullptr);
+    std::vector<uint32_t> k(n, 0u);
+    for (size_t d = 0; d < n; ++d) {
+        rt_ctx* c = g->ctx[d];
+        { int rc = check_gather_args(c, root, "rt_group_render: ctx is NULL"); if (rc != RT_OK) return rc; }
+        RT_HIP(hipSetDevice(c->device));
+        k[d] = c->frames_rendered % (uint32_t)kStreams;
+        { int rc = render_part(c, root, k[d], &part[d]); if (rc != RT_OK) return rc; }
+    }
+    RT_NCCL(ncclGroupStart());
+    int rc = RT_OK;
+    for (size_t d = 0; d < n && rc == RT_OK; ++d) {
+        (void)hipSetDevice(g->ctx[d]->device);
+        rc = exchange_part(g->ctx[d], root, k[d], part[d]);
+    }
+    ncclResult_t ge = ncclGroupEnd();
+    if (rc != RT_OK) return rc;
+    if (ge != ncclSuccess) return fail_nccl(ge, "ncclGroupEnd");
+    for (size_t d = 0; d < n; ++d) {
+        RT_HIP(hipSetDevice(g->ctx[d]->device));
+        { int rc2 = finish_part(g->ctx[d], root, k[d], part[d]); if (rc2 != RT_OK) return rc2; }
+    }
+    return RT_OK;
+}
+
+int rt_group_wait(rt_group* g) {
+    if (!g) return fail(RT_ERR_INVALID_ARG, "rt_group_wait: group is NULL");
+    for (rt_ctx* c : g->ctx) { int rc = rt_wait(c); if (rc != RT_OK) return rc; }
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// rt_ctx.h -- the context behind the C ABI, shared by rt_api.hip (single-GPU entry points) and
+// rt_comm.hip (the RCCL group entry points).  Private to the library.
+#pragma once
+#include "../../include/rt355.h"
+#include "rt_types.h"
+#include "rt_tri_types.h"
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+extern thread_local std::string g_rt_err;      // rt_last_error()
+
+inline int fail(int code, const char* what) {
+    g_rt_err = what;
+    return code;
+}
+inline int fail_hip(hipError_t e, const char* where) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+    g_rt_err = buf;
+    return RT_ERR_HIP;
+}
+#define RT_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return fail_hip(e_, #call);              \
+    } while (0)
+
+// Frames the library itself keeps concurrent (rt_render rotates over this many streams and colour
+// buffers).  Why: at the end of a frame every lane of the persistent hierarchy kernel still carries
+// a path of up to 2*bounces dependent rays; that tail is latency, not work (0.45 ms of a 2.9 ms C3
+// frame, 0.45 of 0.8 ms when 8 ranks share the frame).  Frames in flight each take a share of the
+// chip (RtFrameArgs::grid_share), so one frame's tail runs beside the others' bulk.
+constexpr int kStreams = 4;
+constexpr size_t kCounterBytes = (size_t)RT_RAY_COUNTERS * RT_RAY_COUNTER_STRIDE;   // partial ray counters of one frame
+constexpr size_t kCtrlBytes = kCounterBytes + 32u;                                   // + the 32-byte control block
+
+struct rt_comm_state;   // rt_comm.hip
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;        // uploads, read-back, and frames 0, 3, 6 ... of rt_render (= streams[0])
+    hipStream_t streams[kStreams] = {nullptr};   // rt_render rotates: consecutive frames may overlap on the device
+    hipEvent_t ev_prep0[RT355_MAX_IN_FLIGHT] = {nullptr}, ev_k0[RT355_MAX_IN_FLIGHT] = {nullptr},
+               ev_k1[RT355_MAX_IN_FLIGHT] = {nullptr};
+    hipEvent_t ev_scene = nullptr;       // the scene arrays / hierarchy a frame reads are complete ...
+    hipStream_t scene_stream = nullptr;  // ... recorded on this stream
+    uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
+    hipStream_t slot_stream[RT355_MAX_IN_FLIGHT] = {nullptr};   // the stream each of them was enqueued on
+    uint32_t frames_rendered = 0;        // rt_render calls: parity selects stream and colour buffer
+    uint32_t W = 0, H = 0;
+    uint32_t rank = 0, world = 1;
+    float params[24] = {0};
+    bool have_params = false;
+    bool prep_spheres_valid = false;     // prep_spheres ran since the last rt_write_spheres
+    bool prep_params_valid = false;      // ... and since the last rt_write_params (camera / light records)
+    float* d_records = nullptr;
+    uint32_t n = 0, cap_n = 0;
+    bool have_spheres = false;
+    float4* d_scene = nullptr;           // 8 float4 arrays of n16: geo lgt cam col geo_f lgt_f cam_f + {geo_w,lgt_w,cam_w,-}
+    uint32_t n16 = 0;                    // n rounded up to a multiple of 16
+    float scene_bound = 0.0f;            // max over spheres of |center| + radius (host side)
+    // bounding-sphere hierarchy (rt_bvh.hip): host copy of the records it is built from, the
+    // build result and its device copy
+    std::vector<float> h_records;
+    std::vector<float> h_bvh_rec;
+    std::vector<uint32_t> h_bvh_link;
+    float4* d_bvh_rec = nullptr;
+    uint32_t* d_bvh_link = nullptr;
+    uint32_t bvh_cap = 0, bvh_nodes = 0;
+    bool bvh_valid = false;              // built for the current spheres
+    uint8_t* d_face[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t face_texel0[6] = {0, 0, 0, 0, 0, 0};   // first texel (rgb) of each face: a one-texel sky of one colour is "flat"
+    uint8_t* d_out = nullptr;              // colour buffer of the LATEST rt_render (one of d_outs)
+    uint8_t* d_outs[kStreams] = {nullptr};
+    size_t out_bytes = 0;
+    // per frame in flight: RT_RAY_COUNTERS partial ray counters (kCtrlBytes - 32 bytes), then a 32-byte
+    // control block: unused u64, queue count, queue head, pixel / tile-pair cursor
+    unsigned long long* d_rays = nullptr;
+    float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
+    size_t queue_cap = 0;                  // entries
+    unsigned long long* h_rays = nullptr;  // pinned copy of the latest frame's partial counters
+    // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
+    struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };
+    DevBuf d_tri, d_nodes, d_blas, d_tri_lookup, d_blas_lookup, d_tex;
+    uint32_t tex_w = 0, tex_h = 0;
+    int scene_kind = 0;                    // 0 spheres, 1 triangles: the primitive type written last
+    int mode = RT_MODE_FAST;
+    int variant = 0;
+    int kernel = RT_KERNEL_RAYTRACER;
+    rt_stats stats = {};
+    rt_comm_state* comm = nullptr;         // RCCL communicator + gather buffers (rt_comm_init / rt_group_create)
+};
+
+// rt_api.hip (defined inside its extern "C" block; not exported through include/rt355.h)
+#define RT_INTERNAL __attribute__((visibility("hidden")))
+extern "C" {
+RT_INTERNAL int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s);   // prep + ray-trace launches of one frame into `dst` on `s`
+RT_INTERNAL int rt_drain(rt_ctx* c);                                  // waits for the frames in flight
+RT_INTERNAL uint32_t rt_local_tiles(const rt_ctx* c);
+}
+// rt_comm.hip
+RT_INTERNAL void rt_comm_release(rt_ctx* c);                          // called by rt_destroy
+RT_INTERNAL int rt_comm_after_wait(rt_ctx* c);                        // called by rt_wait once the frames in flight are complete
+
+

@@ -35,10 +35,77 @@ __device__ __forceinline__ v3 texel(const uint8_t* __restrict__ f, int w, int h,
 }
 __device__ __forceinline__ v3 lerp3(v3 a, v3 b, float f) { return add(a, scale(f, sub(b, a))); }
 
-// flat: every face is a single texel (wave-uniform, the constant sky of the BASELINE configs):
-// all four taps are that texel, c, and lerp(c, c, w) = c + w * (c - c) is c for finite weights and
-// NaN otherwise -- the sample is formed as c + (wu * 0 + wv * 0), the same values with one fetch.
-__device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = nullptr, bool flat = false) {
+// ---- seamless cube filtering (oracle/rt_oracle.c: cube_fold, cube_tap) -------------------------------
+// A WebGPU cube texture is six equal square layers and filters seamlessly across its edges (Vulkan
+// "Cube Map Edge Handling"): a bilinear tap one step outside the selected face is the texel of the
+// adjacent face that touches the crossed edge at the same position along it.  Integer geometry: the
+// texel centre (S, T) = (2i+1-n, 2j+1-n) of `face` as a 3-D point with the face planes at +-n, folded
+// over the edge (the coordinate that left the cube becomes the major axis at +-n, the old major axis
+// drops to +-(n-1)) and read back through the face table of the new face.
+__device__ inline void cube_fold(int face, int i, int j, int n, int& nf, int& ni, int& nj) {
+    const int S = 2 * i + 1 - n, T = 2 * j + 1 - n, m = n - 1;
+    int x, y, z;
+    if (face == 0)      { x = n;  y = -T; z = -S; }    // +X: sc = -z, tc = -y
+    else if (face == 1) { x = -n; y = -T; z = S;  }    // -X: sc = +z, tc = -y
+    else if (face == 2) { x = S;  y = n;  z = T;  }    // +Y: sc = +x, tc = +z
+    else if (face == 3) { x = S;  y = -n; z = -T; }    // -Y: sc = +x, tc = -z
+    else if (face == 4) { x = S;  y = -T; z = n;  }    // +Z: sc = +x, tc = -y
+    else                { x = -S; y = -T; z = -n; }    // -Z: sc = -x, tc = -y
+    const int major = face >> 1;
+    const bool ox = major != 0 && (x > m || x < -m);
+    const bool oy = major != 1 && (y > m || y < -m);
+    if (major == 0) x = x > 0 ? m : -m;
+    else if (major == 1) y = y > 0 ? m : -m;
+    else z = z > 0 ? m : -m;
+    int S2, T2;
+    if (ox)      { nf = x > 0 ? 0 : 1; S2 = x > 0 ? -z : z; T2 = -y; }
+    else if (oy) { nf = y > 0 ? 2 : 3; S2 = x; T2 = y > 0 ? z : -z; }
+    else         { nf = z > 0 ? 4 : 5; S2 = z > 0 ? x : -x; T2 = -y; }
+    ni = (S2 + m) >> 1;
+    nj = (T2 + m) >> 1;
+}
+
+__device__ __forceinline__ v3 cube_texel_at(const RtFrameArgs& A, int face, int n, int x, int y, const float* lut) {
+    const uint8_t* f = A.face[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+        if (face == i) f = A.face[i];
+    const uchar4 p = *reinterpret_cast<const uchar4*>(f + 4u * ((size_t)y * (size_t)n + (size_t)x));
+    if (lut) return V(lut[p.x], lut[p.y], lut[p.z]);
+    return V((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f);
+}
+
+// One bilinear tap.  Beyond a corner no face holds the texel: a + ((b - a) + (c - a)) / 3 with a = this
+// face's corner texel and b / c the corner texels of the faces across the u / v edge (Vulkan "Cube Map
+// Corner Handling": the mean of the three, and exactly their value when they agree).
+__device__ inline v3 cube_tap(const RtFrameArgs& A, int face, int n, int i, int j, const float* lut) {
+    const bool oi = i < 0 || i >= n, oj = j < 0 || j >= n;
+    if (!oi && !oj) return cube_texel_at(A, face, n, i, j, lut);
+    const int ci = i < 0 ? 0 : (i >= n ? n - 1 : i), cj = j < 0 ? 0 : (j >= n ? n - 1 : j);
+    int f2, i2, j2;
+    if (oi && oj) {
+        const v3 a = cube_texel_at(A, face, n, ci, cj, lut);
+        cube_fold(face, i, cj, n, f2, i2, j2);
+        const v3 b = cube_texel_at(A, f2, n, i2, j2, lut);
+        cube_fold(face, ci, j, n, f2, i2, j2);
+        const v3 c = cube_texel_at(A, f2, n, i2, j2, lut);
+        return add(a, divs(add(sub(b, a), sub(c, a)), 3.0f));
+    }
+    cube_fold(face, i, j, n, f2, i2, j2);
+    return cube_texel_at(A, f2, n, i2, j2, lut);
+}
+
+// A.sky_flat (host: every face is one texel and the six texels agree -- the constant sky of the
+// BASELINE configs C1-C4): every tap is that texel c, lerp(c, c, w) = c + w * (c - c) is c for finite
+// weights and NaN otherwise, and the corner value is c + (0 + 0) / 3 = c -- the sample is formed as
+// c + (wu * 0 + wv * 0), the same values with one fetch.
+// A.sky_seamless (host: six equal squares): seamless filtering as above; otherwise (not a WebGPU cube)
+// the taps clamp to the edge of the selected image.
+// SKY: 0 = both decided at run time (wave-uniform flags), 1 = the caller's kernel is compiled for a flat
+// sky only (the filtering code is not even instantiated: the hierarchy kernel runs at its VGPR cap and must
+// not pay for it in the BASELINE configs C1-C4), 2 = compiled for a textured sky only.
+template <int SKY = 0>
+__device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = nullptr) {
     const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
     int face; float sc, tc, ma;
     if (az >= ax && az >= ay) {
@@ -63,10 +130,21 @@ __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = 
     const float fu = floorf(u), fv = floorf(v);
     const float wu = u - fu, wv = v - fv;
     const int x0 = (int)fu, y0 = (int)fv;
-    if (flat) {
+    if (SKY == 1 || (SKY == 0 && A.sky_flat)) {
         const v3 c = texel(f, 1, 1, 0, 0, lut);
         const float z = wu * 0.0f + wv * 0.0f;
         return V(c.x + z, c.y + z, c.z + z);
+    }
+    if (SKY == 1) return V(0, 0, 0);   // not reached
+    if (A.sky_seamless && x0 >= -1 && x0 < w && y0 >= -1 && y0 < w) {
+        v3 top = V(0, 0, 0), row = V(0, 0, 0);
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {          // one copy of the tap code for both rows
+            top = row;
+            const v3 a = cube_tap(A, face, w, x0, y0 + k, lut), b = cube_tap(A, face, w, x0 + 1, y0 + k, lut);
+            row = lerp3(a, b, wu);
+        }
+        return lerp3(top, row, wv);
     }
     const v3 c00 = texel(f, w, h, x0, y0, lut), c10 = texel(f, w, h, x0 + 1, y0, lut);
     const v3 c01 = texel(f, w, h, x0, y0 + 1, lut), c11 = texel(f, w, h, x0 + 1, y0 + 1, lut);

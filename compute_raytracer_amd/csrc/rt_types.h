@@ -44,6 +44,8 @@ struct RtFrameArgs {
     const float* cam_w;
     const uint8_t* face[6];    // cube faces, rgba8unorm
     uint32_t fw[6], fh[6];
+    uint32_t sky_flat;         // every face is ONE texel and the six texels agree (the constant sky of C1-C4)
+    uint32_t sky_seamless;     // six equal square faces = a WebGPU cube texture: seamless filtering across edges
     uint8_t* out;              // compact tile buffer [n_local_tiles*8][W][4]
     unsigned long long* rays;  // scene-traversal counter: RT_RAY_COUNTERS partial sums (one atomicAdd per wave)
     // path queue between the first-bounce kernel and the path kernel (two-kernel pipeline):

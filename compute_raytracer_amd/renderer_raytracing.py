@@ -143,6 +143,36 @@ class RendererRaytracing:
         abi.check(self._lib.rt_assemble_frame(self._ctx, ctypes.c_void_p(gathered_ptr), ctypes.c_void_p(frame_ptr),
                                               world, ctypes.c_void_p(stream_ptr) if stream_ptr else None), self._ctx)
 
+    # ---- multi-GPU behind the C ABI: render + RCCL gather + de-interleave in one call ---------------
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128 bytes every rank passes to comm_init (hand them over by any side channel)."""
+        buf = ctypes.create_string_buffer(abi.RT355_COMM_ID_BYTES)
+        abi.check(abi.load().rt_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """Collective over the group (ncclCommInitRank on this context's device); fixes the partition."""
+        if len(unique_id) != abi.RT355_COMM_ID_BYTES:
+            raise ValueError("comm_init: the unique id is %d bytes" % abi.RT355_COMM_ID_BYTES)
+        buf = ctypes.create_string_buffer(bytes(unique_id), abi.RT355_COMM_ID_BYTES)
+        abi.check(self._lib.rt_comm_init(self._ctx, buf, rank, world), self._ctx)
+        self.rank, self.world = int(rank), int(world)
+
+    def render_gather(self, root=0, wait=False):
+        """RR:434-470 across the group: this rank's tiles, the RCCL exchange and the de-interleave are
+        enqueued by ONE library call.  root = -1: every rank receives the frame."""
+        self.recalculateScene()
+        abi.check(self._lib.rt_render_gather(self._ctx, int(root)), self._ctx)
+        if wait:
+            abi.check(self._lib.rt_wait(self._ctx), self._ctx)
+
+    def read_frame(self):
+        """The whole W x H frame of the latest render_gather (on a rank that received it)."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        abi.check(self._lib.rt_read_frame(self._ctx, out.ctypes.data, out.nbytes), self._ctx)
+        return out
+
     def close(self):
         if self._ctx is not None:
             self._lib.rt_destroy(self._ctx)

@@ -19,10 +19,12 @@
  *   - byte layouts are exactly the ones RR writes (f32 indices and counts,
  *     vec3 padded to 16 B), so buffers captured from a browser run replay unchanged.
  *   - a context is bound to ONE device and is not thread-safe (single JS thread in
- *     the reference).  Multi-GPU = one process and one context per GPU; the frame
- *     is split into 8-row tiles (one WGSL workgroup row, RK:73), tile t is rendered
- *     by rank t % world, and the host gathers the compact per-rank tile buffers
- *     with RCCL (see rt_set_partition, rt_render_to, rt_assemble_frame).
+ *     the reference).  Multi-GPU: the frame is split into 8-row tiles (one WGSL
+ *     workgroup row, RK:73), tile t is rendered by rank t % world, and the LIBRARY
+ *     moves the compact per-rank tile buffers over RCCL (xGMI) and de-interleaves
+ *     them: rt_comm_init + rt_render_gather (one process per GPU) or rt_group_create +
+ *     rt_group_render (one process, all GPUs).  rt_set_partition / rt_render_to /
+ *     rt_assemble_frame remain for hosts that bring their own transport.
  *   - there is no CPU fallback anywhere in this library.
  */
 #ifndef RT355_H
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RT355_ABI_VERSION 1
+#define RT355_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -44,7 +46,8 @@ typedef enum rt_status {
     RT_ERR_HIP = -3,          /* a HIP runtime call failed (message has the hipError)   */
     RT_ERR_UNSUPPORTED = -4,  /* combination not supported (e.g. heatmap of a sphere scene) */
     RT_ERR_STATE = -5,        /* call order: e.g. render before resize / write_params   */
-    RT_ERR_CAPACITY = -6      /* destination buffer too small                           */
+    RT_ERR_CAPACITY = -6,     /* destination buffer too small                           */
+    RT_ERR_COMM = -7          /* an RCCL call failed (message has the ncclResult)        */
 } rt_status;
 
 typedef enum rt_kernel {
@@ -74,6 +77,9 @@ typedef struct rt_stats {
     uint32_t batch_frames;        /* renders completed by the last rt_wait                  */
     float batch_kernel_ms;        /* sum of their ray-trace kernel times (hipEvents on the
                                      stream each kernel was launched on)                    */
+    float gather_ms;              /* rt_render_gather / rt_group_render: RCCL exchange + de-interleave of the
+                                     last frame (hipEvents, same stream); kernel_ms then is the render alone */
+    float batch_gather_ms;        /* ... summed over the frames the last rt_wait completed   */
 } rt_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------- */
@@ -189,6 +195,47 @@ int rt_assemble_frame(rt_ctx* ctx, const void* gathered, void* frame, uint32_t w
 /* Device address of the colour buffer of the latest rt_render (valid until the next
  * rt_render / rt_resize / rt_destroy). */
 int rt_device_pixels(rt_ctx* ctx, void** out_ptr, size_t* out_bytes);
+
+/* ---- multi-GPU: render + RCCL gather behind one call (RR:434-470 across a group of GPUs) ------ */
+
+/* One process per GPU.  Rank 0 calls rt_comm_unique_id and hands the bytes to the other ranks by
+ * any side channel (a TCP store, MPI, a file); then EVERY rank calls rt_comm_init on its context
+ * (collective: ncclCommInitRank on the context's device).  It fixes the context's partition to
+ * (rank, world) as rt_set_partition does. */
+#define RT355_COMM_ID_BYTES 128
+int rt_comm_unique_id(uint8_t id[RT355_COMM_ID_BYTES]);
+int rt_comm_init(rt_ctx* ctx, const uint8_t id[RT355_COMM_ID_BYTES], uint32_t rank, uint32_t world);
+int rt_comm_destroy(rt_ctx* ctx);      /* back to a single-GPU context (rank 0 of 1) */
+
+/* Collective; replaces RendererRaytracing.render()'s submit (RR:442-446, 465) for the whole group:
+ * this rank's tiles are rendered, exchanged over RCCL on the same stream and de-interleaved into the
+ * row-major W x H frame.  root >= 0: only that rank receives (grouped ncclSend / ncclRecv -- each
+ * rank's tiles travel once, over its direct xGMI link to the root); root = -1: every rank receives
+ * (ncclAllGather).  Returns after enqueueing; rt_wait completes it.  Frames enqueued back to back
+ * overlap on the device as with rt_render (four streams / buffer sets).  Every rank of the group must
+ * make the same sequence of rt_render_gather calls with the same root. */
+int rt_render_gather(rt_ctx* ctx, int root);
+
+/* The frame of the latest rt_render_gather on a rank that received it: device address (valid until
+ * four more frames are enqueued / rt_resize / rt_destroy), or a copy to host memory (waits first;
+ * cap >= W*H*4).  RT_ERR_STATE on a rank that did not receive.  rt_read_pixels / rt_device_pixels
+ * keep returning this rank's own tiles. */
+int rt_frame_pixels(rt_ctx* ctx, void** out_ptr, size_t* out_bytes);
+int rt_read_frame(rt_ctx* ctx, uint8_t* dst, size_t cap);
+
+/* One process, all GPUs -- the shape of the reference's host, ONE JavaScript thread (src/app.ts):
+ * a context per device (n_devices = 0: every visible device) joined by ncclCommInitAll.  Scene and
+ * parameters are written per member: for (i < rt_group_size(g)) rt_write_*(rt_group_ctx(g, i), ...).
+ * rt_group_render enqueues the render on every device, the exchange (one RCCL group over all
+ * devices) and the de-interleave; rt_group_wait completes it; the frame is read from the root's
+ * context with rt_read_frame / rt_frame_pixels (root = -1: from any member). */
+typedef struct rt_group rt_group;
+int rt_group_create(int n_devices, rt_group** out);
+int rt_group_destroy(rt_group* g);
+int rt_group_size(const rt_group* g);
+rt_ctx* rt_group_ctx(rt_group* g, int i);
+int rt_group_render(rt_group* g, int root);
+int rt_group_wait(rt_group* g);
 
 /* ---- diagnostics -------------------------------------------------------------------------- */
 

@@ -24,9 +24,54 @@ def _normalize(x, y, z):
     return x / ln, y / ln, z / ln
 
 
+def _face_point(f, S, T, n):
+    """3-D point (integer, face planes at +-n) of the texel centre S = 2i+1-n, T = 2j+1-n of face f:
+    Vulkan's cube face table (+X: sc=-z tc=-y; -X: sc=+z tc=-y; +Y: sc=+x tc=+z; -Y: sc=+x tc=-z;
+    +Z: sc=+x tc=-y; -Z: sc=-x tc=-y) solved for (x, y, z)."""
+    N = np.full_like(S, n)
+    return {0: (N, -T, -S), 1: (-N, -T, S), 2: (S, N, T), 3: (S, -N, -T), 4: (S, -T, N), 5: (-S, -T, -N)}[f]
+
+
+_NEIGHBOUR_CACHE = {}
+
+
+def _edge_neighbours(n):
+    """For every face and each of its four edges: the (face', i', j') of the texel across the edge,
+    per position along it.  Found WITHOUT the fold arithmetic of rt_oracle.c: the centre of a tap one
+    step outside face f lies on f's extended plane; the texel it stands for is the one of another
+    face whose centre is nearest to that point (distance sqrt(2) texel half-widths, unique)."""
+    if n in _NEIGHBOUR_CACHE:
+        return _NEIGHBOUR_CACHE[n]
+    idx = np.arange(n)
+    border = []           # (face, i, j, point) of every texel in the outermost ring of every face
+    for f in range(6):
+        ii = np.concatenate([idx, idx, np.zeros(n, int), np.full(n, n - 1)])
+        jj = np.concatenate([np.zeros(n, int), np.full(n, n - 1), idx, idx])
+        x, y, z = _face_point(f, 2 * ii + 1 - n, 2 * jj + 1 - n, n)
+        border.append((np.full(ii.shape, f), ii, jj, np.stack([x, y, z], 1).astype(np.int64)))
+    table = {}
+    for f in range(6):
+        others = [b for k, b in enumerate(border) if k != f]
+        of = np.concatenate([b[0] for b in others]); oi = np.concatenate([b[1] for b in others])
+        oj = np.concatenate([b[2] for b in others]); op = np.concatenate([b[3] for b in others])
+        for side, (ti, tj) in {"left": (np.full(n, -1), idx), "right": (np.full(n, n), idx),
+                                "top": (idx, np.full(n, -1)), "bottom": (idx, np.full(n, n))}.items():
+            x, y, z = _face_point(f, 2 * ti + 1 - n, 2 * tj + 1 - n, n)
+            q = np.stack([x, y, z], 1).astype(np.int64)
+            d2 = ((q[:, None, :] - op[None, :, :]) ** 2).sum(-1)
+            k = d2.argmin(1)
+            assert (d2[np.arange(n), k] == 2).all()
+            table[(f, side)] = (of[k], oi[k], oj[k])
+    _NEIGHBOUR_CACHE[n] = table
+    return table
+
+
 def _cube(faces, rx, ry, rz):
     """textureSampleLevel(skyTex, texSamp, dir, 0).rgb (RK:92,123): major-axis face selection
-    (z wins ties over y over x), bilinear in the face, clamp to edge, lerp a + (b-a)*f."""
+    (z wins ties over y over x), bilinear, lerp a + (b-a)*f.  Six equal square faces (a WebGPU cube
+    texture) filter seamlessly across edges, corners take a + ((b-a)+(c-a))/3 of the three texels
+    that meet there (Vulkan "Cube Map Edge / Corner Handling"); anything else clamps to the edge of
+    the selected image."""
     ax, ay, az = np.abs(rx), np.abs(ry), np.abs(rz)
     isz = (az >= ax) & (az >= ay)
     isy = (~isz) & (ay >= ax)
@@ -42,11 +87,16 @@ def _cube(faces, rx, ry, rz):
     out = np.zeros(rx.shape + (3,), F)
     s = F(0.5) * (sc / ma) + F(0.5)
     t = F(0.5) * (tc / ma) + F(0.5)
+    imgs = [np.asarray(f_, np.uint8) for f_ in faces]
+    n0 = imgs[0].shape[1]
+    seamless = all(im.shape[0] == n0 and im.shape[1] == n0 for im in imgs)
+    stack = np.stack([im[..., :3] for im in imgs]) if seamless else None      # [6][n][n][3]
+    nb = _edge_neighbours(n0) if seamless else None
     for f in range(6):
         m = face == f
         if not m.any():
             continue
-        img = np.asarray(faces[f], np.uint8)
+        img = imgs[f]
         h, w = img.shape[:2]
         u = s[m] * F(w) - F(0.5)
         v = t[m] * F(h) - F(0.5)
@@ -55,8 +105,27 @@ def _cube(faces, rx, ry, rz):
         x0, y0 = fu.astype(np.int64), fv.astype(np.int64)
 
         def tex(xx, yy):
-            xx = np.clip(xx, 0, w - 1); yy = np.clip(yy, 0, h - 1)
-            return img[yy, xx, :3].astype(F) / F(255.0)
+            if not seamless:
+                xx = np.clip(xx, 0, w - 1); yy = np.clip(yy, 0, h - 1)
+                return img[yy, xx, :3].astype(F) / F(255.0)
+            cx, cy = np.clip(xx, 0, w - 1), np.clip(yy, 0, w - 1)
+            own = stack[f, cy, cx].astype(F) / F(255.0)
+
+            def across(side_lo, side_hi, coord, along):
+                ff, ii, jj = np.zeros_like(xx), np.zeros_like(xx), np.zeros_like(xx)
+                for side, sel in ((side_lo, coord < 0), (side_hi, coord >= w)):
+                    tf, ti, tj = nb[(f, side)]
+                    ff[sel] = tf[along[sel]]; ii[sel] = ti[along[sel]]; jj[sel] = tj[along[sel]]
+                return stack[ff, jj, ii].astype(F) / F(255.0)
+            ox, oy = (xx < 0) | (xx >= w), (yy < 0) | (yy >= w)
+            res = own.copy()
+            eu = across("left", "right", xx, cy)      # texel across the u edge, at the (clamped) row
+            ev = across("top", "bottom", yy, cx)      # texel across the v edge, at the (clamped) column
+            only_u, only_v, both = ox & ~oy, oy & ~ox, ox & oy
+            res[only_u] = eu[only_u]
+            res[only_v] = ev[only_v]
+            res[both] = (own + ((eu - own) + (ev - own)) / F(3.0))[both]
+            return res
         c00, c10, c01, c11 = tex(x0, y0), tex(x0 + 1, y0), tex(x0, y0 + 1), tex(x0 + 1, y0 + 1)
         top = c00 + wu * (c10 - c00)
         bot = c01 + wu * (c11 - c01)

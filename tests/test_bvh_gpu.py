@@ -130,7 +130,7 @@ def test_scene_beyond_the_filter_range_is_rendered_literally(oracle, variant):
     assert st["rays"] == rays
 
 
-@pytest.mark.parametrize("kind", ["six_colours_1x1", "one_face_2x2"])
+@pytest.mark.parametrize("kind", ["six_colours_1x1", "one_face_2x2", "cube_5x5"])
 def test_sky_shortcut_for_single_texel_faces(oracle, kind):
     """All faces 1x1 takes the one-fetch form of the cube sample; any larger face the bilinear one."""
     rng = np.random.default_rng(3)
@@ -138,6 +138,8 @@ def test_sky_shortcut_for_single_texel_faces(oracle, kind):
     sky.faces = [rng.integers(0, 256, (1, 1, 4), dtype=np.uint8) for _ in range(6)]
     if kind == "one_face_2x2":
         sky.faces[2] = rng.integers(0, 256, (2, 2, 4), dtype=np.uint8)
+    if kind == "cube_5x5":
+        sky.faces = [rng.integers(0, 256, (5, 5, 4), dtype=np.uint8) for _ in range(6)]
     scene = rt.SceneRaytracing().createScene(synthetic_spheres(200, 21))
     ref, _, rays = oracle_render(oracle, scene, 160, 120, 5, skybox=sky)
     img, st = gpu_render(scene, 160, 120, 5, strict=False, skybox=sky, variant=BVH)

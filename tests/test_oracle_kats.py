@@ -161,21 +161,153 @@ def test_cube_axes(oracle, d, face):
     assert rgb[0] == F(40 * face + 10) / F(255)
 
 
-@pytest.mark.parametrize("d,face", [
-    ((1, 1, 0), 2), ((1, -1, 0), 3), ((-1, 1, 0), 2), ((-1, -1, 0), 3),       # |x| == |y|: y wins over x
-    ((1, 0, 1), 4), ((1, 0, -1), 5), ((-1, 0, 1), 4), ((-1, 0, -1), 5),       # |x| == |z|: z wins
-    ((0, 1, 1), 4), ((0, 1, -1), 5), ((0, -1, 1), 4), ((0, -1, -1), 5),       # |y| == |z|: z wins
+@pytest.mark.parametrize("d,face,other", [
+    ((1, 1, 0), 2, 0), ((1, -1, 0), 3, 0), ((-1, 1, 0), 2, 1), ((-1, -1, 0), 3, 1),       # |x| == |y|: y wins over x
+    ((1, 0, 1), 4, 0), ((1, 0, -1), 5, 0), ((-1, 0, 1), 4, 1), ((-1, 0, -1), 5, 1),       # |x| == |z|: z wins
+    ((0, 1, 1), 4, 2), ((0, 1, -1), 5, 2), ((0, -1, 1), 4, 3), ((0, -1, -1), 5, 3),       # |y| == |z|: z wins
 ])
-def test_cube_edges_tie_break(oracle, d, face):
+def test_cube_edges_tie_break(oracle, d, face, other):
+    """A direction exactly on a cube edge: seamless filtering blends half of the winning face with half
+    of the face across the edge (the out-of-face tap is the low one on a left / top edge, the high one
+    on a right / bottom edge).  Which face won is not observable here -- that is the point of seamless
+    filtering --; the tie-break itself is pinned below with a non-cube set of images."""
     rgb = oracle.cube_sample(_numbered_faces(), d)
-    assert rgb[0] == F(40 * face + 10) / F(255)
+    own, nbr = F(40 * face + 10) / F(255), F(40 * other + 10) / F(255)
+    assert rgb[0] in (own + F(0.5) * (nbr - own), nbr + F(0.5) * (own - nbr))
+    # unequal images (not a WebGPU cube): taps stay inside the winning face -> its colour alone
+    faces = _numbered_faces()
+    spoil = [f for f in range(6) if f not in (face, other)][0]
+    faces[spoil] = np.zeros((2, 3, 4), np.uint8)
+    assert oracle.cube_sample(faces, d)[0] == own
+
+
+def _dir_of(face, s, t):
+    """Direction through the point (s, t) in [0,1]^2 of `face` (inverse of Vulkan's face table)."""
+    sc, tc = 2.0 * s - 1.0, 2.0 * t - 1.0
+    return {0: (1.0, -tc, -sc), 1: (-1.0, -tc, sc), 2: (sc, 1.0, tc), 3: (sc, -1.0, -tc),
+            4: (sc, -tc, 1.0), 5: (-sc, -tc, -1.0)}[face]
+
+
+def _id_faces(n):
+    """face id in red, texel column in green, texel row in blue"""
+    faces = []
+    for f in range(6):
+        img = np.zeros((n, n, 4), np.uint8)
+        img[..., 0] = 40 * f + 10
+        img[..., 1] = (np.arange(n) * 20)[None, :]
+        img[..., 2] = (np.arange(n) * 20)[:, None]
+        img[..., 3] = 255
+        faces.append(img)
+    return faces
+
+
+# Hand-derived from the face table (sc/tc per face): which texel lies across an edge.
+#   +X left edge (z = +1):  +Z's right column, same row        (both have tc = -y)
+#   +Y bottom edge (z = +1): +Z's top row, same column         (both have sc = +x)
+#   +Y right edge (x = +1):  +X's top row, column n-1-j        (+Y: tc = +z, +X: sc = -z)
+#   -Y left edge (x = -1):   -X's bottom row, column n-1-j     (-Y: tc = -z, -X: sc = +z)
+#   -Z right edge (x = -1):  -X's left column, same row
+@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("face,edge,nbr", [
+    (0, "left", lambda n, k: (4, n - 1, k)), (2, "bottom", lambda n, k: (4, k, 0)),
+    (2, "right", lambda n, k: (0, n - 1 - k, 0)), (3, "left", lambda n, k: (1, n - 1 - k, n - 1)),
+    (5, "right", lambda n, k: (1, 0, k)),
+])
+def test_cube_edge_taps_come_from_the_adjacent_face(oracle, n, face, edge, nbr):
+    faces = _id_faces(n)
+    for k in range(n):
+        c = (k + 0.5) / n                       # a texel centre along the edge: one row / column of taps only
+        s, t = {"left": (0.0, c), "right": (1.0, c), "top": (c, 0.0), "bottom": (c, 1.0)}[edge]
+        i, j = {"left": (0, k), "right": (n - 1, k), "top": (k, 0), "bottom": (k, n - 1)}[edge]
+        f2, i2, j2 = nbr(n, k)
+        rgb = oracle.cube_sample(faces, _dir_of(face, s, t))
+        own = faces[face][j, i, :3].astype(F) / F(255)
+        other = faces[f2][j2, i2, :3].astype(F) / F(255)
+        # the out-of-face tap is the low one on a left / top edge (weight 0.5 either way)
+        want = other + F(0.5) * (own - other) if edge in ("left", "top") else own + F(0.5) * (other - own)
+        assert np.array_equal(rgb, want), (face, edge, k, rgb, want)
+
+
+def _random_cube(seed, n):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, (n, n, 4), dtype=np.uint8) for _ in range(6)]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_cube_is_continuous_across_all_12_edges_and_8_corners(oracle, n):
+    """Implementation-free property of seamless filtering: the colour seen just inside one face equals
+    the colour seen just inside the neighbour (clamp-to-edge filtering jumps by O(1) on random faces)."""
+    faces = _random_cube(100 + n, n)
+    rng = np.random.default_rng(n)
+    eps = 1e-6
+    worst = 0.0
+    for a in range(3):                          # edges: two coordinates at +-1, the third free
+        b, c = (a + 1) % 3, (a + 2) % 3
+        for sb in (-1.0, 1.0):
+            for sc_ in (-1.0, 1.0):
+                for free in list(rng.uniform(-1, 1, 12)) + [-1.0, 1.0]:     # ... and the corners
+                    d = np.zeros(3)
+                    d[a], d[b], d[c] = free, sb, sc_
+                    lo = d.copy(); lo[b] *= (1 - eps)          # just inside the face of axis c
+                    hi = d.copy(); hi[c] *= (1 - eps)          # just inside the face of axis b
+                    ca, cb = oracle.cube_sample(faces, tuple(lo)), oracle.cube_sample(faces, tuple(hi))
+                    worst = max(worst, float(np.abs(ca - cb).max()))
+    assert worst < 2e-5 * n, worst
+
+
+def test_cube_corner_is_the_mean_of_the_three_corner_texels(oracle):
+    """Exactly at a corner all four taps carry weight 1/4: two edge texels, this face's corner texel and
+    the corner value a + ((b-a)+(c-a))/3 -- together the mean of the three texels meeting there."""
+    faces = _random_cube(7, 2)
+    for d in [(1, 1, 1), (-1, 1, 1), (1, -1, 1), (1, 1, -1), (-1, -1, 1), (-1, 1, -1), (1, -1, -1), (-1, -1, -1)]:
+        rgb = oracle.cube_sample(faces, d)
+        # the three texels: per incident face, the texel nearest the corner
+        tex = []
+        for f in range(6):
+            axis, positive = f >> 1, (f & 1) == 0
+            if (d[axis] > 0) != positive:
+                continue
+            best, bd = None, 1e9
+            for j in range(2):
+                for i in range(2):
+                    p = np.array(_dir_of(f, (i + 0.5) / 2, (j + 0.5) / 2))
+                    dist = np.abs(p - np.array(d, float)).sum()
+                    if dist < bd:
+                        best, bd = faces[f][j, i, :3].astype(np.float64) / 255.0, dist
+            tex.append(best)
+        assert len(tex) == 3
+        assert np.abs(rgb - np.mean(tex, axis=0)).max() < 1e-6
+    # equal texels give exactly that value (Vulkan: "must have that value")
+    flat = [np.full((1, 1, 4), 77, np.uint8) for _ in range(6)]
+    for d in [(1, 1, 1), (-1, 1, -1), (0.3, -1, 1)]:
+        assert np.array_equal(oracle.cube_sample(flat, d), np.full(3, F(77) / F(255)))
+
+
+def test_cube_of_unequal_or_non_square_images_clamps_inside_the_face(oracle):
+    """Not a WebGPU cube texture (the C ABI accepts it): taps never leave the selected image."""
+    faces = _numbered_faces()
+    faces[3] = np.zeros((2, 3, 4), np.uint8)
+    for d, face in [((1, 1, 0), 2), ((1, 0, -1), 5), ((0, 1, 1), 4)]:
+        assert oracle.cube_sample(faces, d)[0] == F(40 * face + 10) / F(255)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 16])
+def test_cube_c_oracle_equals_numpy_restatement_on_random_directions(oracle, n):
+    from oracle import rt_oracle_np as onp
+    faces = _random_cube(n, n)
+    rng = np.random.default_rng(50 + n)
+    d = rng.normal(size=(4000, 3)).astype(F)
+    d[:600] = np.sign(d[:600]) * np.where(rng.random((600, 3)) < 0.6, 1.0, np.abs(d[:600])).astype(F)   # edges, corners
+    got = np.stack([oracle.cube_sample(faces, tuple(v)) for v in d])
+    want = onp._cube(faces, d[:, 0].copy(), d[:, 1].copy(), d[:, 2].copy())
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def test_cube_texel_orientation(oracle):
     # +X face: sc = -z, tc = -y -> looking along +x, +y is up (row 0), -z is right... u grows with -z
     faces = _numbered_faces()
-    up_left = oracle.cube_sample(faces, (1, 0.9, 0.9))      # sc=-0.9 -> u small, tc=-0.9 -> v small: texel (0,0)
-    low_right = oracle.cube_sample(faces, (1, -0.9, -0.9))  # texel (1,1)
+    up_left = oracle.cube_sample(faces, (1, 0.5, 0.5))      # sc=-0.5, tc=-0.5: the centre of texel (0,0)
+    low_right = oracle.cube_sample(faces, (1, -0.5, -0.5))  # the centre of texel (1,1)
     assert up_left[1] == F(0) and low_right[1] == F(1.0)
 
 

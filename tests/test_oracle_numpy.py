@@ -17,6 +17,7 @@ def random_sky(seed, w=5, h=7):
 
 
 CASES = [
+    (96, 64, 20, 4, "cube"), (64, 48, 40, 3, "cube1"),
     (96, 64, 20, 4, "const"), (64, 48, 64, 8, "random"), (33, 17, 3, 1, "random"), (40, 40, 0, 3, "random"),
     (50, 30, 7, 16, "const"), (8, 8, 130, 2, "random"),
 ]
@@ -26,7 +27,8 @@ CASES = [
 def test_c_oracle_equals_numpy_restatement(oracle, W, H, N, B, sky):
     scene = rt.synthetic_scene(N, 1000 + N)
     p, s = scene.pack_params(B), scene.pack_spheres()
-    faces = (rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA) if sky == "const" else random_sky(N)).faces
+    faces = (rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA) if sky == "const" else
+             random_sky(N, 4, 4) if sky == "cube" else random_sky(N, 1, 1) if sky == "cube1" else random_sky(N)).faces
     a, af, ar = oracle.render(p, s, faces, W, H, want_float=True)
     b, bf, br = onp.render(p, s, faces, W, H)
     assert np.array_equal(af.view(np.uint32), bf.view(np.uint32))

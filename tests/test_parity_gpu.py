@@ -30,7 +30,8 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def random_sky(seed, w=6, h=5):
+def random_sky(seed, w=6, h=6):
+    """six equal squares by default: a WebGPU cube texture, filtered seamlessly across its edges"""
     rng = np.random.default_rng(seed)
     m = rt.CubemapMaterial()
     m.faces = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for _ in range(6)]
@@ -89,6 +90,7 @@ EDGE = [
     (64, 64, 64, 0, "const"),       # maxBounces 0: white (RK:103,113)
     (64, 64, 64, 1, "const"),
     (72, 56, 1000, 3, "random"),
+    (96, 64, 20, 3, "noncube"),     # 6 x 5 images: not a WebGPU cube, taps clamp inside the face
 ]
 
 
@@ -98,7 +100,8 @@ def test_edge_cases_bit_exact(oracle, W, H, N, B, sky, strict):
     scene = rt.synthetic_scene(N, 9000 + N) if N else rt.synthetic_scene(1, 1)
     if N == 0:
         scene.spheres = []
-    skybox = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA) if sky == "const" else random_sky(W * 31 + N)
+    skybox = (rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA) if sky == "const" else
+              random_sky(W * 31 + N, 6, 5) if sky == "noncube" else random_sky(W * 31 + N))
     ref, _, rays = oracle_render(oracle, scene, W, H, B, skybox=skybox)
     img, st = gpu_render(scene, W, H, B, strict=strict, skybox=skybox)
     assert img.shape == ref.shape
@@ -381,3 +384,80 @@ def test_c4_emulated_ranks_reassemble_the_golden_c3_frame(world):
     got = frame.cpu().numpy()
     assert hashlib.sha256(got.tobytes()).hexdigest() == fr["sha256"]
     assert rays == fr["rays"]
+
+
+# ---- C5 at full size: 7680x4320, 4096 spheres, 16 bounces, 6 x 512^2 textured cube ----------------------
+def _c5():
+    sys_path_golden = os.path.join(G, "make_golden.py")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", sys_path_golden)
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = json.load(open(os.path.join(G, "c5_tiles.json")))
+    cfg, scene = config_inputs("C5")
+    sky = mg.c5_sky()
+    sky_sha = hashlib.sha256(b"".join(np.ascontiguousarray(f).tobytes() for f in sky.faces)).hexdigest()
+    assert sky_sha == g["sky_sha256"], "the procedural C5 sky is not the one the golden tiles were rendered under"
+    assert hashlib.sha256(scene.pack_spheres().tobytes()).hexdigest() == g["scene_sha256"]
+    assert (cfg["width"], cfg["height"], cfg["spheres"], cfg["bounces"]) == (7680, 4320, 4096, 16)
+    return g, cfg, scene, sky
+
+
+def test_c5_full_size_against_golden_tiles_and_strict(oracle):
+    """BASELINE config C5 at its full size.  The oracle's rows for 10 of the 540 tiles and 256 sparse
+    pixels (64 of them next to cube-face edges) are committed (tests/golden/c5_tiles.json, generated
+    by make_golden.py --c5); the fast frame must reproduce them, equal the strict (literal) frame
+    bit for bit, and -- if the oracle's full-frame hash is on file -- hash to it."""
+    g, cfg, scene, sky = _c5()
+    W, H, B = cfg["width"], cfg["height"], cfg["bounces"]
+    fast, st_fast = gpu_render(scene, W, H, B, strict=False, skybox=sky)
+    for t in g["tiles"]:
+        rows = fast[8 * t["tile"]:8 * t["tile"] + 8]
+        if hashlib.sha256(rows.tobytes()).hexdigest() != t["sha256"]:
+            ref, _, _ = oracle_render(oracle, scene, W, H, B, skybox=sky, tile_first=t["tile"], tile_step=(H + 7) // 8)
+            bad = np.argwhere((rows != ref[8 * t["tile"]:8 * t["tile"] + 8]).any(-1))
+            raise AssertionError("C5 tile %d differs from the oracle at %d pixels, first (row, x) %s"
+                                 % (t["tile"], len(bad), bad[:4].tolist()))
+    for px in g["pixels"]:
+        assert list(fast[px["y"], px["x"]]) == px["rgba8"], px
+    strict, st_strict = gpu_render(scene, W, H, B, strict=True, skybox=sky)
+    assert np.array_equal(fast, strict)
+    assert st_fast["rays"] == st_strict["rays"]
+    assert np.all(fast[..., 3] == 255)
+    if "frame_sha256" in g:
+        assert hashlib.sha256(fast.tobytes()).hexdigest() == g["frame_sha256"]
+        assert st_fast["rays"] == g["frame_rays"]
+
+
+def test_c5_eight_emulated_ranks_reassemble_the_one_rank_frame():
+    """C5 is specified on 8 GPUs: 540 tiles -> 68 / 67 per rank.  One GPU plays the 8 ranks in turn;
+    the de-interleaved frame must equal the frame one rank renders alone, ray counts must add up."""
+    import torch
+    g, cfg, scene, sky = _c5()
+    W, H, B = cfg["width"], cfg["height"], cfg["bounces"]
+    world = 8
+    full, st_full = gpu_render(scene, W, H, B, strict=False, skybox=sky)
+    msg = tiles.message_bytes(W, H, world)
+    gathered = torch.zeros(world * msg, dtype=torch.uint8, device="cuda")
+    frame = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ren = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky)
+    L = abi.load()
+    rays, counts = 0, []
+    try:
+        for r in range(world):
+            abi.check(L.rt_set_partition(ren._ctx, r, world), ren._ctx)
+            ren.rank, ren.world = r, world
+            part = gathered[r * msg:(r + 1) * msg]
+            ren.render_to(part.data_ptr(), part.numel(), stream)
+            ren.wait()
+            st = ren.stats()
+            counts.append(st["local_tiles"])
+            rays += st["rays"]
+        ren.assemble_frame(gathered.data_ptr(), frame.data_ptr(), world, stream)
+        torch.cuda.synchronize()
+    finally:
+        ren.close()
+    assert counts == [68, 68, 68, 68, 67, 67, 67, 67]
+    assert np.array_equal(frame.cpu().numpy().reshape(H, W, 4), full)
+    assert rays == st_full["rays"]
