@@ -7,18 +7,31 @@ BASELINE.json's configuration C3 (3840x2160, 1024 spheres, 8 bounces), on N GPUs
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one frame: per-frame scene preparation + the ray-trace kernel over this rank's row
-tiles (+ for N > 1 the RCCL all-gather of the tiles and the de-interleave into the full frame
-on every rank).  Scene, cube map and parameters are resident in HBM before the timed region.
-"ray" = one scene traversal (primary/reflection RK:114 + shadow RK:153); the per-frame count is
-the kernel's own exact counter (tests check it against the oracle).
+tiles and -- for N > 1 -- the RCCL exchange of the tiles and their de-interleave into the full
+frame, all enqueued by ONE C-ABI call (rt_render_gather, include/rt355.h: the library owns the
+communicator).  torch.distributed is used for the control plane only (gloo: hands rank 0's RCCL
+unique id to the other ranks, barriers, the max-over-ranks of the timings).  Scene, cube map and
+parameters are resident in HBM before the timed region.  "ray" = one scene traversal
+(primary/reflection RK:114 + shadow RK:153); the per-frame count is the kernel's own exact counter
+(tests check it against the oracle).
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the ray-trace kernel)
-against the FP32 vector peak, which is the roof that binds this path; the HBM
-fraction the north_star asks for is reported inside it as `hbm`.  `cpu_baseline` times the CPU
-oracle (the repository's own scalar restatement of the shader: kind "port") on a bounded sample
-of the same frame.
+Prints ONE JSON line on rank 0.
+  * value / ms_per_step: K frames enqueued back to back (up to four overlap on the device);
+    serial_ms_per_step: the same frames one at a time (render + wait, the reference's
+    `await onSubmittedWorkDone`, RR:467), timed separately after the main region.
+  * roofline: the binding roof of this path is FP32 VALU issue, not HBM.  `achieved`
+    prices what the dominant kernel EXECUTES: VALU wave-instructions per launch (PMC pass committed
+    under profiles/, summarised by tools/pmc_summary.py into profiles/traffic.json -- `from_profile`
+    says which) x 128 fp32 flop slots (a wave64 VALU instruction holds a SIMD-32 for 2 cycles, 32
+    lanes x 2 flop each: the unit the 157.3 TFLOP/s vector peak is made of) / the frame time.  frac <= 1.
+    The ALGORITHMIC rate of the reference's test-every-sphere loop (25 flop x N x rays / time) is kept
+    apart as `algorithmic_speedup_vs_bruteforce`.  The HBM fraction the north_star asks for is `hbm`.
+  * frame_check: sha256 of the last timed frame against tests/golden/frames.json (the oracle's frame).
+  * cpu_baseline: the CPU oracle (the repository's scalar restatement of the shader: kind "port") on a
+    bounded sample of the same frame.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,14 +41,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Four frames are kept in flight on four streams, next to RCCL's stream and the library's own: with
+# Four frames are kept in flight on four streams, next to RCCL's kernels and the library's copies: with
 # HIP's default of 4 hardware queues several of them share one queue and serialise (measured: 3.67
 # instead of 2.43 ms per frame through the N > 1 path).  Must be set before the HIP runtime loads.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FLOP_PER_TEST = 25          # WGSL-literal count of HK:308-311
-PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)"
+PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)" = 1024 SIMDs x 64 flop/clk x 2.4 GHz
+FLOP_SLOTS_PER_VALU = 128   # one wave64 VALU instruction = 2 cycles of a SIMD-32 = 2 x 32 lanes x 2 flop
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+FLIGHT = 4                  # frames the library keeps concurrent (rt_ctx rotates over 4 streams / buffer sets)
 
 
 def parse():
@@ -47,13 +62,17 @@ def parse():
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--serial", action="store_true",
-                    help="one frame at a time (render + wait, as the reference does, RR:467); default: frames are "
-                         "enqueued back to back and up to four overlap on the device")
+                    help="the MAIN timed region runs one frame at a time (render + wait, RR:467); default: frames "
+                         "are enqueued back to back and up to four overlap on the device")
+    ap.add_argument("--serial-steps", type=int, default=-1,
+                    help="frames of the separate one-at-a-time measurement (default min(steps, 20); 0: skip)")
+    ap.add_argument("--gather", default="root", choices=["root", "all"],
+                    help="N > 1: tiles go to rank 0 only (grouped ncclSend/ncclRecv) or to every rank (ncclAllGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--force-dist", action="store_true",
-                    help="take the N>1 code path (render_to + all-gather + assemble) even with one rank; "
-                         "used by tests/test_bench_gpu.py to exercise that path on a 1-GPU box")
+                    help="take the N>1 code path (rt_comm_init + rt_render_gather) even with one rank; used by "
+                         "tests/test_bench_gpu.py to exercise that path on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -87,6 +106,27 @@ def cpu_baseline(cfg, scene, sky, target_s):
     }
 
 
+def kernel_label(mode, variant, N):
+    hierarchy = mode == "fast" and (variant == 4 or (variant == 0 and N >= 128))
+    queue_pipeline = mode == "fast" and not hierarchy and (variant in (2, 3) or (variant in (0, 4, 5) and N >= 320))
+    if mode == "strict":
+        return "trace_pixels<FILTER=false> (literal loop)", hierarchy, queue_pipeline
+    if hierarchy:
+        return "bvh_pixels (bounding-sphere hierarchy, one persistent kernel per frame)", hierarchy, queue_pipeline
+    if queue_pipeline:
+        return "first_bounce + trace_paths (brute force, one frame's ray-trace launches)", hierarchy, queue_pipeline
+    return "trace_pixels (brute force, single kernel)", hierarchy, queue_pipeline
+
+
+def golden_frame(name):
+    """sha256 / rays of the oracle's frame for a BASELINE config, if committed (C4 is the C3 frame)."""
+    try:
+        fr = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))
+        return fr.get("C3" if name == "C4" else name)
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +137,7 @@ def main():
             sys.exit("bench.py: --gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
 
-    import torch  # device memory, streams and torch.distributed only
+    import torch  # torch.distributed (control plane) and torch.cuda.synchronize only; no tensor touches the data path
     import compute_raytracer_amd as rt
     from compute_raytracer_amd import tiles
     from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
@@ -105,14 +145,14 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
     multi = world > 1 or a.force_dist
+    dist = None
     if multi:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:          # --force-dist without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"),
                               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")              # control plane; the pixels travel over RCCL inside librt355.so
 
     name = a.config or ("C3" if world == 1 else "C4")
     if name not in rt.BASELINE_CONFIGS:
@@ -126,176 +166,184 @@ def main():
     else:
         sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
 
-    r = rt.RendererRaytracing(W, H, scene, device=local_rank, maxBounces=B, rank=rank, world=world)
+    r = rt.RendererRaytracing(W, H, scene, device=local_rank, maxBounces=B)
     r.initialize(sky)
     r.set_mode(a.mode == "strict")
     r.set_variant(a.variant)
+    root = 0 if a.gather == "root" else -1
+    if multi:
+        ids = [rt.RendererRaytracing.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        r.comm_init(ids[0], rank, world)              # collective: ncclCommInitRank on this rank's GPU
     r.recalculateScene()   # uploads: scene resident in HBM before anything is timed
 
-    FLIGHT = 4                          # frames kept concurrent (the library rotates rt_render over 4 streams itself)
-    if multi:
-        msg = tiles.message_bytes(W, H, world)
-        # frame k runs on stream k % 4: render of this rank's tiles, all-gather (RCCL's stream, ordered
-        # after the render), de-interleave; four frames are in flight, each with its own buffers
-        streams = [torch.cuda.Stream() for _ in range(FLIGHT)]
-        local = [torch.zeros(msg, dtype=torch.uint8, device="cuda") for _ in range(FLIGHT)]
-        gathered = [torch.empty(world * msg, dtype=torch.uint8, device="cuda") for _ in range(FLIGHT)]
-        frames = [torch.empty(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(FLIGHT)]
-        frame = frames[0]
-        torch.cuda.synchronize()
-    pending = []       # [(work, buffer index)] gathers whose frame is not assembled yet
-    counter = [0]
-
-    def finish_oldest():
-        work, k = pending.pop(0)
-        with torch.cuda.stream(streams[k]):
-            work.wait()                                               # stream k waits for the gather
-            r.assemble_frame(gathered[k].data_ptr(), frames[k].data_ptr(), world, streams[k].cuda_stream)
-
-    def step():
-        if not multi:
-            r.enqueue()                       # prep + ray-trace kernel; the library rotates its streams
-            if a.serial:
-                r.wait()
+    def step(serial):
+        if multi:
+            r.render_gather(root)         # this rank's tiles + RCCL exchange + de-interleave: one C-ABI call
         else:
-            k = counter[0] % FLIGHT
-            counter[0] += 1
-            while len(pending) >= FLIGHT:     # buffer set k is free once its previous frame is assembled
-                finish_oldest()
-            with torch.cuda.stream(streams[k]):
-                r.render_to(local[k].data_ptr(), local[k].numel(), streams[k].cuda_stream)   # this rank's tiles
-                work = dist.all_gather_into_tensor(gathered[k], local[k], async_op=True)      # RCCL over xGMI
-            pending.append((work, k))
-            if a.serial:
-                while pending:
-                    finish_oldest()
-                torch.cuda.synchronize()
+            r.enqueue()                   # prep + ray-trace kernel; the library rotates its streams
+        if serial:
+            r.wait()
 
     def fence():
-        if multi:
-            while pending:                    # every step's frame is assembled inside the timed region
-                finish_oldest()
-            torch.cuda.synchronize()
-            dist.barrier()
+        r.wait()
         torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+            r.wait()
+
+    def timed(steps, serial):
+        """-> (elapsed s, kernel ms sum, gather ms sum, frames with event times)"""
+        kms = gms = 0.0
+        frames = 0
+        fence()
+        t0 = time.perf_counter()
+        done = 0
+        while done < steps:
+            chunk = min(steps - done, 64)     # stay inside the library's event ring (RT355_MAX_IN_FLIGHT)
+            for _ in range(chunk):
+                step(serial)
+            done += chunk
+            if done < steps:
+                r.wait()
+                st = r.stats()
+                kms += st["batch_kernel_ms"]; gms += st["batch_gather_ms"]; frames += st["batch_frames"]
+        fence()
+        elapsed = time.perf_counter() - t0
+        st = r.stats()
+        kms += st["batch_kernel_ms"]; gms += st["batch_gather_ms"]; frames += st["batch_frames"]
+        return elapsed, kms, gms, frames      # (serial: every rt_wait is a batch of one; the caller samples instead)
 
     for _ in range(a.warmup):
-        step()
-    fence()
-    r.wait()
-    kernel_ms_sum, kernel_frames = 0.0, 0
-    t0 = time.perf_counter()
-    done = 0
-    while done < a.steps:
-        chunk = min(a.steps - done, 64)       # stay inside the library's event ring (RT355_MAX_IN_FLIGHT)
-        for _ in range(chunk):
-            step()
-        done += chunk
-        if done < a.steps:
-            r.wait()
+        step(a.serial)
+    elapsed, kms, gms, kframes = timed(a.steps, a.serial)
+    rays_local = r.stats()["rays"]
+    if a.serial:                      # every rt_wait reports its own batch of one: sample the per-frame times afterwards
+        kms = gms = 0.0
+        kframes = 0
+        for _ in range(min(a.steps, 8)):
+            step(True)
             st = r.stats()
-            kernel_ms_sum += st["batch_kernel_ms"]
-            kernel_frames += st["batch_frames"]
-    fence()
-    elapsed = time.perf_counter() - t0
-    r.wait()
-    st = r.stats()
-    kernel_ms_sum += st["batch_kernel_ms"]
-    kernel_frames += st["batch_frames"]
-    rays_local = st["rays"]
+            kms += st["kernel_ms"]; gms += st["gather_ms"]; kframes += 1
+
+    # the last timed frame, hashed against the oracle's frame of this config
+    check = None
+    gold = golden_frame(name)
+    if gold is not None and (not multi or rank == 0 or root < 0):
+        frame = r.read_frame() if multi else r.read_pixels()
+        check = {"sha256_matches_oracle_frame": hashlib.sha256(frame.tobytes()).hexdigest() == gold["sha256"],
+                 "golden": "tests/golden/frames.json[%s]" % ("C3" if name == "C4" else name)}
+
+    # one frame at a time, separately timed
+    ssteps = min(a.steps, 20) if a.serial_steps < 0 else a.serial_steps
+    serial_ms = None
+    if a.serial:
+        serial_ms = elapsed / a.steps * 1e3
+    elif ssteps > 0:
+        s_elapsed, _, _, _ = timed(ssteps, True)
+        serial_ms = s_elapsed / ssteps * 1e3
 
     if multi:
-        t = torch.tensor([elapsed, float(rays_local), kernel_ms_sum / max(kernel_frames, 1)],
-                         dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(rays_local), kms / max(kframes, 1), gms / max(kframes, 1), serial_ms or 0.0],
+                         dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         rays_frame = int(round(float(tsum[1])))
-        kernel_ms = float(tmax[2])            # slowest rank's average kernel time
+        kernel_ms = float(tmax[2])            # slowest rank's average render time
+        gather_ms = float(tmax[3])
+        serial_ms = float(tmax[4]) if serial_ms is not None else None
         rays_kernel = rays_frame / world      # average rays per launch
     else:
         rays_frame = rays_local
-        kernel_ms = kernel_ms_sum / max(kernel_frames, 1)
+        kernel_ms = kms / max(kframes, 1)
+        gather_ms = 0.0
         rays_kernel = rays_frame
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = rays_frame * a.steps / elapsed / 1e6
-        # which kernels rendered the frame (the library's rule, rt_api.hip: enqueue)
-        hierarchy = a.mode == "fast" and (a.variant == 4 or (a.variant == 0 and N >= 128))
-        flops_launch = FLOP_PER_TEST * N * rays_kernel
-        # launches of consecutive frames overlap on the device (each on a share of the chip), so the
-        # chip-level rate is flops per launch / frame period; one frame at a time: / the launch duration
-        # the two-kernel brute-force pipeline shares a path queue: its frames are serialised (rt_api.hip)
-        queue_pipeline = (a.mode == "fast" and not hierarchy and
-                          (a.variant in (2, 3) or (a.variant in (0, 4, 5) and N >= 320)))
+        label, hierarchy, queue_pipeline = kernel_label(a.mode, a.variant, N)
+        # launches of consecutive frames overlap on the device (each on a share of the chip): the chip-level
+        # rate is work per launch / frame period; one frame at a time: / the launch duration.  The two-kernel
+        # brute-force pipeline shares a path queue: its frames are serialised by the library.
         overlapping = not a.serial and not queue_pipeline
-        in_flight = FLIGHT if overlapping else 1
         roof_ms = ms_per_step if overlapping else kernel_ms
-        achieved_tf = flops_launch / (roof_ms * 1e-3) / 1e12
+        flops_alg = FLOP_PER_TEST * N * rays_kernel
         local_rows = tiles.tiles_of_rank(H, 0, world) * 8
         hbm_bytes = 4 * W * min(local_rows, H) + 32 * N + 96          # SURVEY.md 8(d)
         hbm_gbps = hbm_bytes / (roof_ms * 1e-3) / 1e9
-        if a.mode == "strict":
-            kernel_label = "trace_pixels<FILTER=false> (literal loop)"
-        elif hierarchy:
-            kernel_label = "bvh_pixels (bounding-sphere hierarchy, one persistent kernel per frame)"
-        elif N >= 320 and a.variant in (0, 5):
-            kernel_label = "first_bounce + trace_paths (brute force, one frame's ray-trace launches)"
-        else:
-            kernel_label = "trace_pixels (brute force, single kernel)"
-        roof_note = ("achieved = 25 flop x N spheres x rays per launch / time: the ALGORITHMIC work of the "
-                     "reference's test-every-sphere loop (SURVEY.md 8(d)); time = the launch duration (kernel_ms_avg, "
-                     "HIP events) when frames run one at a time (--serial), the frame period when launches of "
-                     "consecutive frames overlap (launches_in_flight = 4, each on a quarter of the chip: kernel_ms_avg is "
-                     "then ~4 frame periods)."
-                     + (" The hierarchy evaluates ~5 % of those tests, so frac > 1 means 'faster than brute force could "
-                        "run at the FP32 roof'; the executed-instruction view is in `executed`." if hierarchy else ""))
-        executed = None
-        traffic = None
+
+        # executed work of the dominant kernel, from the committed PMC summary (tools/pmc_summary.py)
+        prof, prof_key, estimated = None, None, False
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                key = "%s/%s/v%d/n%d" % (name, a.mode, a.variant, world)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-                executed = tj.get(key, {}).get("executed")      # PMC-derived, from the committed profile
+                prof_key = "%s/%s/v%d/n%d" % (name, a.mode, a.variant, world)
+                prof = tj.get(prof_key)
+                if prof is None and world > 1:      # per-rank launches of the row-tiled frame: 1/world of the one-GPU launch
+                    prof_key = "%s/%s/v%d/n1" % ("C3" if name == "C4" else name, a.mode, a.variant)
+                    prof = tj.get(prof_key)
+                    estimated = prof is not None
             except Exception:
-                traffic = None
+                prof = None
+        valu = (prof or {}).get("executed", {}).get("valu_wave_insts_per_launch")
+        if valu is not None and estimated:
+            valu = valu / world
+        roof = {"bound": "valu-issue (fp32 vector pipe)", "kernel": label, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "kernel_ms_avg": kernel_ms, "time_ms": roof_ms,
+                "launches_in_flight": FLIGHT if overlapping else 1}
+        if valu is not None:
+            ach = valu * FLOP_SLOTS_PER_VALU / (roof_ms * 1e-3) / 1e12
+            roof.update({
+                "achieved": ach, "frac": ach / PEAK_FP32_TFLOPS,
+                "valu_wave_insts_per_launch": valu,
+                "from_profile": {"key": prof_key, "files": prof.get("source_files"), "kernel": prof.get("kernel"),
+                                 "per_rank_estimate_insts_over_world": estimated},
+                "traffic": None if estimated else prof.get("hbm_bytes_per_launch"),
+                "basis": "achieved = VALU wave-instructions the kernel executes per launch (PMC SQ_INSTS_VALU, from_profile) x 128 "
+                         "fp32 flop slots (2 SIMD-32 cycles x 32 lanes x 2) / time_ms; peak = 1024 SIMDs x 64 flop/clk x 2.4 GHz. "
+                         "time_ms = frame period with launches_in_flight frames overlapping, else the launch duration.",
+            })
+            if serial_ms is not None and not queue_pipeline:
+                s_ach = valu * FLOP_SLOTS_PER_VALU / (serial_ms * 1e-3) / 1e12
+                roof["serial"] = {"time_ms": serial_ms, "achieved": s_ach, "frac": s_ach / PEAK_FP32_TFLOPS}
+        else:
+            roof.update({"achieved": None, "frac": None, "traffic": None,
+                         "basis": "no PMC pass for %s under profiles/: executed-instruction roofline not available" % prof_key})
+        roof["hbm"] = {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
+                       "bytes_per_launch": hbm_bytes}
+        alg_tf = flops_alg / (roof_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/s at %dx%d, %d spheres, %d bounces" % (W, H, N, B),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "frames_per_s": 1e3 / ms_per_step,
+            "serial_ms_per_step": serial_ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d, %d spheres (seed %d), %d bounces, constant sky, reference default "
-                                   "camera/light" % (name, W, H, N, cfg["seed"], B),
+            "config": {"workload": "%s: %dx%d, %d spheres (seed %d), %d bounces, %s, reference default camera/light"
+                                   % (name, W, H, N, cfg["seed"], B, "6x512^2 procedural sky cube" if cfg["skybox"] else "constant sky"),
                        "mode": a.mode, "variant": a.variant, "rays_per_frame": rays_frame,
-                       "parallelism": "row-tiles x%d%s" % (world, "" if world == 1 else " + RCCL all-gather")},
-            "roofline": {
-                "bound": "valu-fp32", "kernel": kernel_label,
-                "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / PEAK_FP32_TFLOPS,
-                "traffic": traffic,
-                "kernel_ms_avg": kernel_ms, "flop_per_launch": flops_launch, "launches_in_flight": in_flight,
-                "note": roof_note,
-                "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": hbm_gbps / PEAK_HBM_GBPS, "bytes_per_launch": hbm_bytes},
-            },
+                       "frames_in_flight": 1 if a.serial else FLIGHT,
+                       "parallelism": "row-tiles x%d%s" % (world, "" if not multi else
+                                                           " + RCCL %s inside librt355 (rt_render_gather)" %
+                                                           ("gather to rank 0" if root == 0 else "all-gather"))},
+            "roofline": roof,
+            "algorithmic_speedup_vs_bruteforce": {
+                "value": alg_tf / PEAK_FP32_TFLOPS, "algorithmic_tflops": alg_tf, "flop_per_launch": flops_alg,
+                "note": "25 flop x N spheres x rays per launch / time_ms against the fp32 vector peak: how much faster the frame "
+                        "is produced than a kernel that really examined every (ray, sphere) pair could at that peak"},
+            "frame_check": check,
         }
-        if executed is not None:
-            out["roofline"]["executed"] = executed
+        if multi:
+            out["gather_ms_avg"] = gather_ms
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, scene, sky, a.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    if multi and rank == 0 and os.environ.get("RT355_BENCH_CHECK_FRAME"):
-        # test hook: hash of the assembled frame, to compare with the single-kernel path
-        import hashlib
-        torch.cuda.synchronize()
-        print("frame_sha256 " + hashlib.sha256(frame.cpu().numpy().tobytes()).hexdigest(), file=sys.stderr, flush=True)
     r.close()
     if multi:
         dist.barrier()

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Collects, on the GPU box, the rocprofv3 evidence bench.py's roofline refers to:
+#   kernel-trace stats of the default bench run (pipelined) and of --serial, and the PMC passes of
+#   --serial (SQ counters, FETCH_SIZE, WRITE_SIZE: separate runs, as the MI355X guide prescribes).
+# usage: tools/collect_profiles.sh <round dir under gpurun_out, e.g. r02> [KEY=C3-fast-v0-n1] [bench args ...]
+# Results land in gpurun_out/<round>/prof/; copy what is to be judged into profiles/<round>/ and run
+# tools/pmc_summary.py.
+set -e
+RD=${1:-r02}; shift || true
+KEY=${1:-C3-fast-v0-n1}; shift || true
+OUT=gpurun_out/$RD/prof
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--steps 12 --warmup 3 --no-cpu-baseline --serial-steps 0 $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -o t -- python3 bench.py $ARGS > $OUT/${KEY}__pipelined_bench.json 2> $OUT/trace_pipelined.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -o t -- python3 bench.py $ARGS --serial > $OUT/${KEY}__serial_bench.json 2> $OUT/trace_serial.err
+rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o sq -- python3 bench.py $ARGS --serial > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python3 bench.py $ARGS --serial > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python3 bench.py $ARGS --serial > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+mkdir -p $OUT/collected/pmc
+for p in sq fetch write; do
+  f=$(find $OUT/pmc_$p -name "*counter_collection.csv" | head -n 1)
+  [ -n "$f" ] && cp "$f" $OUT/collected/pmc/${KEY}__$p.csv
+done
+for m in pipelined serial; do
+  f=$(find $OUT/trace_$m -name "*kernel_stats.csv" | head -n 1)
+  [ -n "$f" ] && cp "$f" $OUT/collected/${KEY}__${m}_kernel_stats.csv
+  cp $OUT/${KEY}__${m}_bench.json $OUT/collected/
+done
+ls -la $OUT/collected $OUT/collected/pmc
+# development passes (not needed by bench.py): where the idle issue slots go
+if [ -n "$RT_EXTRA_PASSES" ]; then
+  rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o lds -- python3 bench.py $ARGS --serial > $OUT/pmc_lds.json 2> $OUT/pmc_lds.err
+  rocprofv3 --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $OUT/pmc_stall -o stall -- python3 bench.py $ARGS --serial > $OUT/pmc_stall.json 2> $OUT/pmc_stall.err
+  for p in lds stall; do
+    f=$(find $OUT/pmc_$p -name "*counter_collection.csv" | head -n 1)
+    [ -n "$f" ] && cp "$f" $OUT/collected/pmc/${KEY}__$p.csv
+  done
+fi
