@@ -493,6 +493,9 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             if (!known) seen[distinct++] = o;
         }
         fa.grid_share = distinct;
+        // a caller that has been enqueuing frames back to back gets equal shares from the first frame of a
+        // batch on (rt_bvh.hip: launch_bvh_as); one that waits after every frame keeps the whole chip
+        if (c->pipelined_hint) fa.grid_share = (uint32_t)kStreams;
     }
 
     // this frame's partial ray counters and its 32-byte control block: one of RT355_MAX_IN_FLIGHT
@@ -573,6 +576,7 @@ int rt_wait(rt_ctx* c) {
         c->stats.rays = 0;
         for (uint32_t k = 0; k < RT_RAY_COUNTERS; ++k) c->stats.rays += c->h_rays[k * (RT_RAY_COUNTER_STRIDE / 8u)];
         c->stats.batch_frames = c->in_flight;
+        c->pipelined_hint = c->in_flight > 1u;
         c->stats.batch_kernel_ms = 0.0f;
         for (uint32_t i = 0; i < c->in_flight; ++i) {
             float ms = 0.0f;

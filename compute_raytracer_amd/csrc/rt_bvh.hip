@@ -370,7 +370,15 @@ hipError_t launch_bvh_as(const RtFrameArgs& a, size_t lds, hipStream_t s) {
     const uint32_t per_cu = (uint32_t)std::min((size_t)(WAVES == 8 ? 3 : 1), cap / std::max(lds, (size_t)1));
     const uint32_t pixels = a.n_local_tiles * ((a.W + 7u) / 8u) * 64u;
     uint32_t blocks = 256u * (per_cu ? per_cu : 1u);
-    if (a.grid_share > 1u) blocks = std::max(192u, blocks / a.grid_share);   // frames in flight share the chip
+    // Frames in flight share the chip: each takes ONE workgroup per CU (256), whatever their number.  Four
+    // frames then oversubscribe the 768 resident slots: the workgroups of the youngest frame start as those
+    // of the oldest drain, so no slot idles through a frame's tail.  Measured at C3, four frames in flight,
+    // workgroups per frame 192 / 224 / 256 / 288 / 320 / 384: 2.31 / 2.42 / 2.22 / 2.50 / 2.52 / 2.50 ms per
+    // frame.  Equal grids matter as much as their size: a first frame launched with all 768 workgroups makes
+    // the next three start together when it ends, their tails then coincide for the rest of the batch
+    // (2.50 ms); the host therefore asks for the share from the first frame on once it has seen frames
+    // enqueued back to back (rt_api.hip: pipelined_hint).
+    if (a.grid_share > 1u) blocks = std::max(256u, blocks / a.grid_share);
     const uint32_t need = (pixels + 64u * WAVES - 1u) / (64u * WAVES);
     if (blocks > need) blocks = need;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);

@@ -49,6 +49,7 @@ struct rt_ctx {
     uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
     hipStream_t slot_stream[RT355_MAX_IN_FLIGHT] = {nullptr};   // the stream each of them was enqueued on
     uint32_t frames_rendered = 0;        // rt_render calls: parity selects stream and colour buffer
+    bool pipelined_hint = false;         // the last rt_wait completed more than one frame: the caller keeps frames in flight
     uint32_t W = 0, H = 0;
     uint32_t rank = 0, world = 1;
     float params[24] = {0};
