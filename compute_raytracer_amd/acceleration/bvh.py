@@ -1,110 +1,117 @@
-"""BVH -- src/rendering-raycast/acceleration/bvh.ts:7-169: top-down SAH build over a mesh's
-triangles, 9 candidate planes per axis, in-place partition of the index array.  (bvh.ts:171-229,
-the median-split `subdivide`, is unused upstream and not restated.)"""
-import sys
+"""BVH -- the bottom-level tree of one mesh, as src/rendering-raycast/acceleration/bvh.ts:7-169
+defines it (SAH over nine planes per axis at tenths of the node's extent, in-place two-pointer
+partition of the index array, children numbered in depth-first build order), built here with
+numpy: triangle corners and f32 centroids are arrays, every candidate plane of a node is priced
+in one vectorised pass, and the tree grows off an explicit stack.  (bvh.ts:171-229, the
+median-split `subdivide`, is unused upstream and not restated.)
 
-from .. import glmatrix as glm
-from .aabb import AABB
+Why the vector form is exact: the reference grows its candidate boxes in gl-matrix vec3s --
+Float32Arrays --, so every running min / max is rounded to f32 as it is stored (aabb.ts:12-15).
+Rounding to f32 is monotonic, so the f32-rounded running minimum of a sequence is the minimum
+of the f32-rounded members: `np.minimum.reduce` over corners cast to float32 gives the same bits
+(starting values +-1e30 rounded to f32, which an empty side keeps).
+
+`nodes`, `triangleIndices`, `nodesUsed`, `minCorner`, `maxCorner` are what the scene layer reads;
+`minCorner` / `maxCorner` stay at the +-999999 placeholders of bvh.ts:23-25 (nothing upstream
+ever computes them, and the instances' boxes are made from exactly these)."""
+import numpy as np
+
 from .node import Node
+
+_PLANES = 10
+_F32_HUGE = np.float32(1e30)
+
+
+def _area_f32(lo, hi):
+    """2 (ex ey + ey ez + ez ex) with the extents rounded to f32 and the products in f64
+    (aabb.ts:17-20); lo / hi are (..., 3) float32."""
+    e = (hi - lo).astype(np.float32).astype(np.float64)
+    return 2.0 * (e[..., 0] * e[..., 1] + e[..., 1] * e[..., 2] + e[..., 2] * e[..., 0])
 
 
 class BVH:
-    def __init__(self, triangles):                             # bvh.ts:18-28
+    def __init__(self, triangles):
         self.triangles = triangles
-        self.triangleCount = len(triangles)
-        self.nodesUsed = 0
-        MAX_NUMBER = 999999
-        self.minCorner = [MAX_NUMBER] * 3
-        self.maxCorner = [-MAX_NUMBER] * 3
-        self.buildBVH()
+        self.triangleCount = n = len(triangles)
+        self.minCorner = [999999] * 3
+        self.maxCorner = [-999999] * 3
+        corners = np.array([[[float(v) for v in c] for c in t.corners] for t in triangles], dtype=np.float64).reshape(n, 3, 3)
+        centroid = np.array([[np.float32(v) for v in t.centroid] for t in triangles], dtype=np.float32).reshape(n, 3)
+        corners32 = corners.astype(np.float32)
+        order = np.arange(n, dtype=np.int64)
+        cap = max(2 * n - 1, 1)
+        lo = np.full((cap, 3), 1e30)
+        hi = np.full((cap, 3), -1e30)
+        first = np.zeros(cap, dtype=np.int64)
+        count = np.zeros(cap, dtype=np.int64)
 
-    def buildBVH(self):                                        # bvh.ts:30-51
-        self.triangleIndices = list(range(self.triangleCount))
-        self.nodes = [Node() for _ in range(2 * len(self.triangles) - 1)]
-        root = self.nodes[0]
-        root.leftChildIndex = 0
-        root.primitiveCount = len(self.triangles)
-        self.nodesUsed += 1
-        self.updateBounds(0)
-        old = sys.getrecursionlimit()
-        sys.setrecursionlimit(max(old, 10000))
-        try:
-            self.subdivideSAH(0)
-        finally:
-            sys.setrecursionlimit(old)
+        def fit(node):
+            c = corners[order[first[node]:first[node] + count[node]]].reshape(-1, 3)
+            lo[node] = np.minimum(c.min(axis=0), 1e30) if len(c) else 1e30
+            hi[node] = np.maximum(c.max(axis=0), -1e30) if len(c) else -1e30
 
-    def updateBounds(self, nodeIndex):                         # bvh.ts:53-65
-        node = self.nodes[nodeIndex]
-        node.minCorner = [1e30, 1e30, 1e30]
-        node.maxCorner = [-1e30, -1e30, -1e30]
-        lo, hi = node.minCorner, node.maxCorner
-        for i in range(node.primitiveCount):
-            tri = self.triangles[self.triangleIndices[node.leftChildIndex + i]]
-            for c in tri.corners:
-                for k in range(3):
-                    v = c[k]
-                    if v < lo[k]: lo[k] = v
-                    if v > hi[k]: hi[k] = v
-
-    def findBestSplit(self, node):                             # bvh.ts:67-86
-        SPLIT_PER_AXIS = 10
-        bestCost, bestAxis, bestSplitPosition = 1e30, 0, 0
-        for axis in range(3):
-            for noSplit in range(1, SPLIT_PER_AXIS):
-                splitPercent = noSplit / SPLIT_PER_AXIS
-                splitPosition = node.minCorner[axis] * (1 - splitPercent) + node.maxCorner[axis] * splitPercent
-                cost = self.SAH(node, axis, splitPosition)
-                if cost < bestCost:
-                    bestCost, bestAxis, bestSplitPosition = cost, axis, splitPosition
-        return bestAxis, bestSplitPosition, bestCost
-
-    def SAH(self, node, axis, splitPosition):                  # bvh.ts:88-110
-        left, right = AABB(), AABB()
-        nl = nr = 0
-        for i in range(node.primitiveCount):
-            tri = self.triangles[self.triangleIndices[i + node.leftChildIndex]]
-            if float(tri.centroid[axis]) < splitPosition:
-                nl += 1
-                left.grow(tri.corners[0]); left.grow(tri.corners[1]); left.grow(tri.corners[2])
-            else:
-                nr += 1
-                right.grow(tri.corners[0]); right.grow(tri.corners[1]); right.grow(tri.corners[2])
-        return left.surfaceArea() * nl + right.surfaceArea() * nr
-
-    def subdivideSAH(self, nodeIndex):                         # bvh.ts:112-169
-        node = self.nodes[nodeIndex]
-        if node.primitiveCount < 2:
-            return
-        axis, splitPosition, subdivisionCost = self.findBestSplit(node)
-        parent = AABB()
-        parent.grow(node.minCorner)
-        parent.grow(node.maxCorner)
-        parentCost = parent.surfaceArea() * node.primitiveCount
-        if parentCost < subdivisionCost:
-            return
-        i = node.leftChildIndex
-        j = i + node.primitiveCount - 1
-        idx = self.triangleIndices
-        while i <= j:
-            if float(self.triangles[idx[i]].centroid[axis]) < splitPosition:
-                i += 1
-            else:
-                idx[i], idx[j] = idx[j], idx[i]
-                j -= 1
-        leftCount = i - node.leftChildIndex
-        if leftCount == 0 or leftCount == node.primitiveCount:
-            return
-        leftChildIndex = self.nodesUsed
-        self.nodesUsed += 1
-        rightChildIndex = self.nodesUsed
-        self.nodesUsed += 1
-        self.nodes[leftChildIndex].leftChildIndex = node.leftChildIndex
-        self.nodes[leftChildIndex].primitiveCount = leftCount
-        self.nodes[rightChildIndex].leftChildIndex = i
-        self.nodes[rightChildIndex].primitiveCount = node.primitiveCount - leftCount
-        node.leftChildIndex = leftChildIndex
-        node.primitiveCount = 0
-        self.updateBounds(leftChildIndex)
-        self.updateBounds(rightChildIndex)
-        self.subdivideSAH(leftChildIndex)
-        self.subdivideSAH(rightChildIndex)
+        used = 0
+        if n:
+            first[0], count[0], used = 0, n, 1
+            fit(0)
+            todo = [0]
+            while todo:
+                node = todo.pop()
+                cnt = int(count[node])
+                if cnt < 2:
+                    continue
+                run = order[first[node]:first[node] + cnt]
+                cen = centroid[run].astype(np.float64)                 # (cnt, 3): the f32 values, compared in f64
+                c32 = corners32[run]                                   # (cnt, 3 corners, 3)
+                tmin = c32.min(axis=1)                                 # per-triangle f32 boxes
+                tmax = c32.max(axis=1)
+                best, best_axis, best_plane = 1e30, 0, 0.0
+                for axis in range(3):
+                    a, b = float(lo[node, axis]), float(hi[node, axis])
+                    for s in range(1, _PLANES):
+                        f = s / _PLANES
+                        plane = a * (1 - f) + b * f
+                        left = cen[:, axis] < plane
+                        nl = int(left.sum())
+                        cost = 0.0
+                        for side, k in ((left, nl), (~left, cnt - nl)):
+                            smin = np.minimum(tmin[side].min(axis=0), _F32_HUGE) if k else np.full(3, _F32_HUGE, np.float32)
+                            smax = np.maximum(tmax[side].max(axis=0), -_F32_HUGE) if k else np.full(3, -_F32_HUGE, np.float32)
+                            cost = cost + float(_area_f32(smin.astype(np.float32), smax.astype(np.float32))) * k
+                        if cost < best:
+                            best, best_axis, best_plane = cost, axis, plane
+                stay = float(_area_f32(lo[node].astype(np.float32), hi[node].astype(np.float32))) * cnt
+                if stay < best:
+                    continue
+                # the reference's two-pointer sweep (bvh.ts:130-141), on the index run itself: its result is
+                # an order, not just a set, and the order decides how later nodes partition
+                i, j = int(first[node]), int(first[node]) + cnt - 1
+                while i <= j:
+                    if float(centroid[order[i], best_axis]) < best_plane:
+                        i += 1
+                    else:
+                        order[i], order[j] = order[j], order[i]
+                        j -= 1
+                n_left = i - int(first[node])
+                if n_left == 0 or n_left == cnt:
+                    continue
+                left_i, right_i = used, used + 1
+                used += 2
+                first[left_i], count[left_i] = first[node], n_left
+                first[right_i], count[right_i] = i, cnt - n_left
+                first[node], count[node] = left_i, 0
+                fit(left_i)
+                fit(right_i)
+                todo.append(right_i)
+                todo.append(left_i)                                    # the left subtree is numbered first
+        self.nodesUsed = used
+        self.triangleIndices = [int(v) for v in order]
+        self.nodes = []
+        for k in range(cap):
+            nd = Node()
+            if k < used:
+                nd.minCorner = [float(v) for v in lo[k]]
+                nd.maxCorner = [float(v) for v in hi[k]]
+                nd.leftChildIndex = int(first[k])
+                nd.primitiveCount = int(count[k])
+            self.nodes.append(nd)

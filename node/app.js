@@ -17,7 +17,9 @@ async function main() {
   if (!cfg) throw new Error('unknown config ' + name);
   const scene = new SceneRaytracing();
   await scene.createScene(syntheticSpheres(cfg.spheres, cfg.seed));
-  const renderer = new RendererRaytracing(cfg.width, cfg.height, scene, { maxBounces: cfg.bounces });
+  const opts = { maxBounces: cfg.bounces };
+  if (process.argv[6] === 'group') opts.devices = 0;
+  const renderer = new RendererRaytracing(cfg.width, cfg.height, scene, opts);
   await renderer.initialize();
   renderer.setStrict(strict);
   for (let i = 0; i < frames; ++i) {

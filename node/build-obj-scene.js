@@ -2,32 +2,32 @@
 // node node/build-obj-scene.js spec.json [out.rgba]
 // spec: {width,height,bounces,updates:[dt,...], meshes:[{obj:"<OBJ text>",descriptor:{color,alignBottom,invertYZ,scale}}],
 //        models:[{meshIndex,position,eulers,eulerSpeed}], meshTexture:{width,height,data}}
-// Builds the triangle scene ENTIRELY in JS (OBJ reader -> SAH BVH -> models -> TLAS, the reference's
-// createScene path), prints the packed buffers' f32 bit patterns (so that the Python mirror can be
-// compared bit for bit) and, when a GPU is present and out.rgba is given, renders through the addon.
+// Builds the triangle scene ENTIRELY in JS (OBJ text -> soup -> SAH tree -> instances -> top-level tree:
+// the reference's createScene path), prints the f32 bit patterns of the upload buffers (so that the
+// Python mirror can be compared bit for bit) and, when a GPU is present and out.rgba is given, renders
+// through the addon.
 const fs = require('fs');
 const crypto = require('crypto');
-const { SceneRaytracing } = require('./scene-raytracing');
-const { Mesh } = require('./mesh');
-const { Model } = require('./model/model');
+const { SceneRaytracing, loadMesh, makeModel } = require('./scene-raytracing');
 
 async function main() {
   const spec = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
   const scene = new SceneRaytracing();
   await scene.createScene([]);
-  const meshes = spec.meshes.map((m) => new Mesh().initializeFromText(m.obj, m.descriptor));
-  const models = spec.models.map((m) => new Model(m.meshIndex, m.position, m.eulers, m.eulerSpeed));
+  const meshes = spec.meshes.map((m) => loadMesh(m.obj, m.descriptor));
+  const models = spec.models.map((m) => makeModel(m.meshIndex, m.position, m.eulers, m.eulerSpeed));
   scene.createTriangleScene(meshes, models);
   for (const dt of spec.updates || []) scene.update(dt);
-  const bits = (a) => Array.from(new Uint32Array(Float32Array.from(a).buffer));
+  const bits = (a) => Array.from(new Uint32Array(a.buffer, a.byteOffset, a.length));
+  const sha = (a) => crypto.createHash('sha256').update(Buffer.from(a.buffer, a.byteOffset, a.byteLength)).digest('hex');
   const out = {
-    nTriangles: scene.triangles.length, tlasNodesUsed: scene.tlasNodesUsed, tlasNodesMax: scene.tlasNodesMax,
-    blasNodesUsed: scene.blasNodesUsed, blasIndices: scene.blasIndices, triangleIndices: scene.triangleIndices,
-    blas: scene.blasList.map((b) => bits(Array.from(b.inverseModel).concat([b.rootNodeIndex]))),
-    nodes: scene.nodes.map((n) => bits([n.minCorner[0], n.minCorner[1], n.minCorner[2], n.leftChildIndex,
-                                        n.maxCorner[0], n.maxCorner[1], n.maxCorner[2], n.primitiveCount])),
-    tri0: bits([].concat(scene.triangles[0].corners[0], scene.triangles[0].corners[1], scene.triangles[0].corners[2],
-                         Array.from(scene.triangles[0].centroid))),
+    nTriangles: scene.triangleCount, tlasNodesUsed: scene.tlasNodesUsed, tlasNodesMax: scene.tlasNodesMax,
+    blasNodesUsed: scene.blasNodesUsed,
+    blas: bits(scene.frame.blasData), blasIndices: bits(scene.frame.blasIndexData), tlasNodes: bits(scene.frame.nodeDataA),
+    blasNodes: bits(scene.packed.nodeDataB), triangleIndices: bits(scene.packed.triangleIndexData),
+    triangles: bits(scene.packed.triangleData), centroids0: bits(meshes[0].soup.centroid),
+    sha: { triangles: sha(scene.packed.triangleData), blasNodes: sha(scene.packed.nodeDataB), lookup: sha(scene.packed.triangleIndexData),
+           blas: sha(scene.frame.blasData), tlasNodes: sha(scene.frame.nodeDataA) },
   };
   if (process.argv[3]) {
     const { RendererRaytracing } = require('./renderer-raytracing');

@@ -1,18 +1,19 @@
 'use strict';
 // node node/render-json-scene.js scene.json out.rgba [heatmap]
-// Renders a triangle scene given as JSON in the SHAPE of the reference's SceneRaytracing object
-// (camera, light, triangles[{corners,normals,textures,color}], nodes[{minCorner,maxCorner,
-// leftChildIndex,primitiveCount}], blasList[{inverseModel,rootNodeIndex}], blasIndices,
-// triangleIndices, tlasNodesUsed, tlasNodesMax, blasNodesUsed) through RendererRaytracing --
-// i.e. through the same packing code as RR:155-230.  Used by tests/test_node_host.py.
+// Renders a triangle scene whose upload buffers come from somewhere else (a capture of a browser run,
+// the Python mirror): scene.json = {width, height, bounces, camera:{position,forwards,right,up},
+// light:{position,lightIntensity,minIntensity}, tlasNodesMax, packed:{triangleData,nodeDataB,
+// triangleIndexData}, frame:{blasData,blasIndexData,nodeDataA}, meshTexture:{width,height,data}} --
+// number arrays in the layouts of renderer-raytracing.ts:169-229.  Used by tests/test_node_host.py.
 const fs = require('fs');
 const crypto = require('crypto');
 const { RendererRaytracing } = require('./renderer-raytracing');
 
 async function main() {
   const j = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
-  const scene = j.scene;
-  scene.update = () => {};
+  const f32 = (o) => { const r = {}; for (const k of Object.keys(o)) r[k] = Float32Array.from(o[k]); return r; };
+  const scene = { camera: j.camera, light: j.light, spheres: [], hasTriangles: true, tlasNodesMax: j.tlasNodesMax,
+                  packed: f32(j.packed), frame: f32(j.frame), update() {} };
   const renderer = new RendererRaytracing(j.width, j.height, scene, { maxBounces: j.bounces });
   const tex = j.meshTexture ? { width: j.meshTexture.width, height: j.meshTexture.height, data: Uint8Array.from(j.meshTexture.data) } : null;
   await renderer.initialize(null, tex);

@@ -47,13 +47,76 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
     return 1;
 }
 
-static rt_ctx* get_ctx(napi_env env, napi_value v) {
+/* What a JS-side "context" or "group" is: an external pointing at one of these.  The wrapper outlives
+ * rt_destroy (the pointer inside is nulled, so a second destroy or any later use throws instead of
+ * touching freed memory) and carries the "an asynchronous wait is outstanding" flag: rt_ctx is not
+ * thread-safe, and while rt_wait runs on a libuv worker no other call may enter the same context. */
+typedef struct handle {
+    rt_ctx* ctx;             /* NULL once destroyed (or for a group handle) */
+    rt_group* group;         /* group handle: the group; member handle: NULL */
+    struct handle* parent;   /* member of a group: the group's handle (shares its busy flag; not destroyable alone) */
+    int busy;                /* a wait() promise is pending */
+    int members;             /* group handle: member handles alive (they point back at this wrapper) */
+    int collected;           /* group handle: its external is gone; freed with the last member */
+} handle;
+
+static void handle_finalize(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    handle* h = (handle*)data;
+    if (!h) return;
+    if (h->parent) {                      /* a member: its context belongs to the group */
+        handle* g = h->parent;
+        if (--g->members == 0 && g->collected) free(g);
+        free(h);
+        return;
+    }
+    if (!h->busy) {                       /* never free a context a worker thread is still waiting on */
+        if (h->group) { rt_group_destroy(h->group); h->group = NULL; }
+        else if (h->ctx) rt_destroy(h->ctx);
+    }
+    if (h->members > 0) { h->collected = 1; return; }   /* members still look at `group` through this wrapper */
+    free(h);
+}
+
+static handle* get_handle(napi_env env, napi_value v, int want_group) {
     void* p = NULL;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
-        napi_throw_type_error(env, NULL, "rt355: first argument must be a context from create()");
+        napi_throw_type_error(env, NULL, "rt355: first argument must be a context from create() / a group from createGroup()");
         return NULL;
     }
-    return (rt_ctx*)p;
+    handle* h = (handle*)p;
+    if (!want_group && h->parent && !h->parent->group) {
+        napi_throw_error(env, "-5", "rt355: this context belonged to a group that has been destroyed");
+        return NULL;
+    }
+    if (want_group ? !h->group : !h->ctx) {
+        napi_throw_error(env, "-5", want_group ? "rt355: not a live group (destroyed, or a context was passed)"
+                                               : "rt355: not a live context (destroyed, or a group was passed)");
+        return NULL;
+    }
+    if (h->busy || (h->parent && h->parent->busy)) {
+        napi_throw_error(env, "-5", "rt355: an asynchronous wait() on this context is still pending; await it first");
+        return NULL;
+    }
+    return h;
+}
+
+static rt_ctx* get_ctx(napi_env env, napi_value v) {
+    handle* h = get_handle(env, v, 0);
+    return h ? h->ctx : NULL;
+}
+
+static napi_value wrap_handle(napi_env env, rt_ctx* ctx, rt_group* group, handle* parent) {
+    handle* h = (handle*)calloc(1, sizeof *h);
+    if (!h) { napi_throw_error(env, NULL, "rt355: out of memory"); return NULL; }
+    h->ctx = ctx; h->group = group; h->parent = parent;
+    napi_value ext;
+    if (napi_create_external(env, h, handle_finalize, NULL, &ext) != napi_ok) {
+        free(h);
+        napi_throw_error(env, NULL, "rt355: cannot create external");
+        return NULL;
+    }
+    return ext;
 }
 
 static int get_u32(napi_env env, napi_value v, uint32_t* out) {
@@ -101,17 +164,19 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     rt_ctx* ctx = NULL;
     int rc = rt_create(dev, &ctx);
     if (rc != RT_OK) return throw_status(env, rc, NULL);
-    napi_value ext;
-    NAPI_OK(napi_create_external(env, ctx, NULL, NULL, &ext));
+    napi_value ext = wrap_handle(env, ctx, NULL, NULL);
+    if (!ext) rt_destroy(ctx);
     return ext;
 }
 
 static napi_value Destroy(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
-    rt_ctx* ctx = get_ctx(env, argv[0]);
-    if (!ctx) return NULL;
-    rt_destroy(ctx);
+    handle* h = get_handle(env, argv[0], 0);
+    if (!h) return NULL;
+    if (h->parent) { napi_throw_error(env, "-5", "rt355: a group member is destroyed with its group (destroyGroup)"); return NULL; }
+    rt_destroy(h->ctx);
+    h->ctx = NULL;                        /* a second destroy, or any later use, throws */
     return undefined(env);
 }
 
@@ -239,7 +304,7 @@ static napi_value Render(napi_env env, napi_callback_info info) {
 
 /* wait(ctx) -> Promise<void>: rt_wait on a libuv worker so the JS loop is not blocked */
 typedef struct {
-    rt_ctx* ctx;
+    handle* h;               /* busy while the job is queued or running */
     int rc;
     char msg[256];
     napi_deferred deferred;
@@ -249,15 +314,16 @@ typedef struct {
 static void wait_execute(napi_env env, void* data) {
     (void)env;
     wait_job* j = (wait_job*)data;
-    j->rc = rt_wait(j->ctx);
+    j->rc = j->h->group ? rt_group_wait(j->h->group) : rt_wait(j->h->ctx);
     if (j->rc != RT_OK) {   /* rt_last_error is thread-local: fetch it on this thread */
-        strncpy(j->msg, rt_last_error(j->ctx), sizeof j->msg - 1);
+        strncpy(j->msg, rt_last_error(j->h->ctx), sizeof j->msg - 1);
         j->msg[sizeof j->msg - 1] = 0;
     }
 }
 
 static void wait_complete(napi_env env, napi_status status, void* data) {
     wait_job* j = (wait_job*)data;
+    j->h->busy = 0;
     if (status == napi_ok && j->rc == RT_OK) {
         napi_resolve_deferred(env, j->deferred, undefined(env));
     } else {
@@ -270,19 +336,32 @@ static void wait_complete(napi_env env, napi_status status, void* data) {
     free(j);
 }
 
-static napi_value Wait(napi_env env, napi_callback_info info) {
-    napi_value argv[1], promise, name;
-    if (!get_args(env, info, 1, argv)) return NULL;
-    rt_ctx* ctx = get_ctx(env, argv[0]);
-    if (!ctx) return NULL;
+/* wait(ctx) / groupWait(group) -> Promise<void>.  Until it settles every other call on the same context
+ * (or on the group and its members) throws: the C context is single-threaded. */
+static napi_value queue_wait(napi_env env, handle* h) {
+    napi_value promise, name;
     wait_job* j = (wait_job*)calloc(1, sizeof *j);
     if (!j) { napi_throw_error(env, NULL, "rt355: out of memory"); return NULL; }
-    j->ctx = ctx;
+    j->h = h;
     NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
     NAPI_OK(napi_create_string_utf8(env, "rt355.wait", NAPI_AUTO_LENGTH, &name));
     NAPI_OK(napi_create_async_work(env, NULL, name, wait_execute, wait_complete, j, &j->work));
-    NAPI_OK(napi_queue_async_work(env, j->work));
+    h->busy = 1;
+    if (napi_queue_async_work(env, j->work) != napi_ok) {
+        h->busy = 0;
+        napi_throw_error(env, NULL, "rt355: cannot queue the wait");
+        return NULL;
+    }
     return promise;
+}
+
+static napi_value Wait(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    handle* h = get_handle(env, argv[0], 0);
+    if (!h) return NULL;
+    if (h->parent) { napi_throw_error(env, "-5", "rt355: wait for a group member through groupWait()"); return NULL; }
+    return queue_wait(env, h);
 }
 
 static napi_value WaitSync(napi_env env, napi_callback_info info) {
@@ -328,8 +407,137 @@ static napi_value Stats(napi_env env, napi_callback_info info) {
     set_num(env, obj, "prepMs", st.prep_ms);
     set_num(env, obj, "frames", st.frames);
     set_num(env, obj, "mode", st.mode);
+    set_num(env, obj, "batchFrames", st.batch_frames);
+    set_num(env, obj, "batchKernelMs", st.batch_kernel_ms);
+    set_num(env, obj, "gatherMs", st.gather_ms);
+    set_num(env, obj, "batchGatherMs", st.batch_gather_ms);
     return obj;
 }
+
+/* ---- multi-GPU: render + RCCL gather behind one call (include/rt355.h) ------------------------------ */
+
+/* readFrame(ctx, Uint8Array(W*H*4)): the whole frame of the latest renderGather / groupRender */
+static napi_value ReadFrame(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    void* data; size_t len;
+    if (!get_args(env, info, 2, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_typed(env, argv[1], napi_uint8_array, &data, &len)) return NULL;
+    int rc = rt_read_frame(ctx, (uint8_t*)data, len);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+/* one process, all GPUs: createGroup(nDevices (0 = all)) -> group */
+static napi_value CreateGroup(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    int32_t n = 0;
+    if (!get_args(env, info, 1, argv) || !get_i32(env, argv[0], &n)) return NULL;
+    rt_group* g = NULL;
+    int rc = rt_group_create(n, &g);
+    if (rc != RT_OK) return throw_status(env, rc, NULL);
+    napi_value ext = wrap_handle(env, NULL, g, NULL);
+    if (!ext) rt_group_destroy(g);
+    return ext;
+}
+
+static napi_value DestroyGroup(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    handle* h = get_handle(env, argv[0], 1);
+    if (!h) return NULL;
+    rt_group_destroy(h->group);
+    h->group = NULL;      /* member handles check the context pointer the group hands out: see GroupCtx */
+    return undefined(env);
+}
+
+static napi_value GroupSize(napi_env env, napi_callback_info info) {
+    napi_value argv[1], n;
+    if (!get_args(env, info, 1, argv)) return NULL;
+    handle* h = get_handle(env, argv[0], 1);
+    if (!h) return NULL;
+    napi_create_int32(env, rt_group_size(h->group), &n);
+    return n;
+}
+
+/* groupCtx(group, i) -> the member context, for the rt_write_* / resize / setMode calls.  Valid only while
+ * the group lives; the JS side must not keep it past destroyGroup (RendererRaytracing drops them there). */
+static napi_value GroupCtx(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    int32_t i;
+    if (!get_args(env, info, 2, argv)) return NULL;
+    handle* h = get_handle(env, argv[0], 1);
+    if (!h || !get_i32(env, argv[1], &i)) return NULL;
+    rt_ctx* c = rt_group_ctx(h->group, i);
+    if (!c) return throw_status(env, RT_ERR_INVALID_ARG, NULL);
+    napi_value ext = wrap_handle(env, c, NULL, h);
+    if (ext) ++h->members;
+    return ext;
+}
+
+static napi_value GroupRender(napi_env env, napi_callback_info info) {   /* (group, root (-1: every member)) */
+    napi_value argv[2];
+    int32_t root;
+    if (!get_args(env, info, 2, argv)) return NULL;
+    handle* h = get_handle(env, argv[0], 1);
+    if (!h || !get_i32(env, argv[1], &root)) return NULL;
+    int rc = rt_group_render(h->group, root);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, NULL);
+}
+
+static napi_value GroupWait(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    handle* h = get_handle(env, argv[0], 1);
+    return h ? queue_wait(env, h) : NULL;
+}
+
+static napi_value GroupWaitSync(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    handle* h = get_handle(env, argv[0], 1);
+    if (!h) return NULL;
+    int rc = rt_group_wait(h->group);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, NULL);
+}
+
+/* one process per GPU: commUniqueId() -> Uint8Array(128); commInit(ctx, id, rank, world); renderGather(ctx, root) */
+static napi_value CommUniqueId(napi_env env, napi_callback_info info) {
+    (void)info;
+    uint8_t id[RT355_COMM_ID_BYTES];
+    int rc = rt_comm_unique_id(id);
+    if (rc != RT_OK) return throw_status(env, rc, NULL);
+    napi_value ab, ta;
+    void* p = NULL;
+    NAPI_OK(napi_create_arraybuffer(env, RT355_COMM_ID_BYTES, &p, &ab));
+    memcpy(p, id, RT355_COMM_ID_BYTES);
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, RT355_COMM_ID_BYTES, ab, 0, &ta));
+    return ta;
+}
+
+static napi_value CommInit(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    void* data; size_t len;
+    uint32_t rank, world;
+    if (!get_args(env, info, 4, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_typed(env, argv[1], napi_uint8_array, &data, &len) || !get_u32(env, argv[2], &rank) ||
+        !get_u32(env, argv[3], &world))
+        return NULL;
+    if (len != RT355_COMM_ID_BYTES) { napi_throw_range_error(env, NULL, "rt355: the unique id is 128 bytes"); return NULL; }
+    int rc = rt_comm_init(ctx, (const uint8_t*)data, rank, world);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value CommDestroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int rc = rt_comm_destroy(ctx);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+INT_SETTER(RenderGather, rt_render_gather)
 
 static napi_value AbiVersion(napi_env env, napi_callback_info info) {
     (void)info;
@@ -347,6 +555,9 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"setMode", SetMode}, {"setVariant", SetVariant}, {"setPartition", SetPartition}, {"render", Render},
         {"wait", Wait}, {"waitSync", WaitSync}, {"readPixels", ReadPixels}, {"stats", Stats},
         {"abiVersion", AbiVersion},
+        {"readFrame", ReadFrame}, {"createGroup", CreateGroup}, {"destroyGroup", DestroyGroup}, {"groupSize", GroupSize},
+        {"groupCtx", GroupCtx}, {"groupRender", GroupRender}, {"groupWait", GroupWait}, {"groupWaitSync", GroupWaitSync},
+        {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"renderGather", RenderGather},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
         napi_value f;

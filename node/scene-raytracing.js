@@ -1,12 +1,22 @@
 'use strict';
-// SceneRaytracing for sphere scenes -- the counterpart of src/rendering-raycast/scene-raytracing.ts
-// (`spheres: Sphere[]` is declared there, line 18, but never filled).  Same deterministic
-// generator as compute_raytracer_amd/scene_raytracing.py (SURVEY.md 8(d)); BigInt splitmix64.
-const { Camera } = require('./camera');
+// SceneRaytracing -- what src/rendering-raycast/scene-raytracing.ts holds, kept the way the GPU wants it.
+//
+// Sphere scenes: `spheres: Sphere[]` is declared upstream (line 18) but never filled; the deterministic
+// generator below is the one of compute_raytracer_amd/scene_raytracing.py (SURVEY.md 8(d)).
+//
+// Triangle scenes (the reference's live scene, scene-raytracing.ts:73-272): meshes are soups + trees
+// (soup.js, sah.js), instances ("models") are plain records, and everything the renderer uploads is
+// produced directly as the Float32Arrays of renderer-raytracing.ts:169-229 -- no Node / BLAS / Triangle
+// objects in between.  The static part (triangles, bottom-level nodes with their indices already
+// rebased, the triangle lookup) is packed once; the per-frame part (instance matrices, top-level tree)
+// is rebuilt by update(dt), as the reference rebuilds its TLAS every frame (scene-raytracing.ts:138-143).
+const { Camera, deg2rad } = require('./camera');
 const { Sphere } = require('./sphere');
-const { vec3 } = require('./gl-matrix-lite');
-const { Node } = require('./acceleration/node');
-const { BLAS } = require('./acceleration/blas');
+const { mat4 } = require('./gl-matrix-lite');
+const { parseObj } = require('./soup');
+const { buildTree } = require('./sah');
+
+const fround = Math.fround;
 
 const M64 = (1n << 64n) - 1n;
 const BASELINE_CONFIGS = {
@@ -47,132 +57,176 @@ function syntheticSpheres(n, seed) {
   return spheres;
 }
 
+// one mesh: triangles + bottom-level tree (mesh.ts:16-21)
+function loadMesh(objText, descriptor) {
+  const soup = parseObj(objText, descriptor);
+  return { soup, tree: buildTree(soup), triangleLookupOffset: 0, rootNodeIndex: 0 };
+}
+
+// one instance (model/model.ts:11-17); `model` is its column-major matrix
+function makeModel(meshIndex, position, eulers, eulerSpeed) {
+  const m = { meshIndex, position, eulers, eulerSpeed: eulerSpeed ? eulerSpeed.valueOf() : [0, 0, 0], model: null };
+  placeModel(m);
+  return m;
+}
+function placeModel(m) {                                   // model.ts:33-37: translate, then rotate about y
+  m.model = mat4.create();
+  mat4.translate(m.model, m.model, m.position);
+  mat4.rotateY(m.model, m.model, deg2rad(m.eulers[1]));
+}
+function turnModel(m, dt) {                                // model.ts:19-31: the increment is an f32 vector
+  for (let a = 0; a < 3; ++a) {
+    m.eulers[a] = m.eulers[a] + fround(m.eulerSpeed[a] * dt);
+    if (m.eulers[a] > 360) m.eulers[a] -= 360;
+  }
+  for (let a = 0; a < 3; ++a) if (m.eulers[a] < -360) m.eulers[a] += 360;
+  placeModel(m);
+}
+
 class SceneRaytracing {
   constructor() {
     this.camera = null; this.light = null; this.spheres = [];
-    // triangle-scene members, scene-raytracing.ts:19-35
-    this.meshes = []; this.models = []; this.triangles = []; this.triangleIndices = [];
-    this.nodes = []; this.blasList = []; this.blasIndices = [];
-    this.tlasNodesMax = 0; this.tlasNodesUsed = 0; this.blasNodesUsed = 0; this.blasConsumed = false;
+    this.meshes = []; this.models = [];
+    this.triangleCount = 0;
+    this.tlasNodesMax = 0; this.tlasNodesUsed = 0; this.blasNodesUsed = 0;
+    this.packed = null;          // static buffers: { triangleData, nodeDataB, triangleIndexData }
+    this.frame = null;           // per-frame buffers: { blasData, blasIndexData, nodeDataA }
   }
+  get hasTriangles() { return this.triangleCount > 0; }
+
   async createScene(spheres) {                                       // scene-raytracing.ts:37-45
     this.camera = new Camera([0.0593, 2.692, 3.293], 106, 270);
     this.light = { position: [0, 5, 0], lightIntensity: 3.0, minIntensity: 0.3 };
     this.spheres = spheres || [];
     return this;
   }
+
   update(dt) {                                                       // scene-raytracing.ts:138-143
-    if (this.models.length) {
-      for (const model of this.models) model.update(dt);
-      this.buildBVH();
-    }
+    if (!this.models.length) return;
+    for (const m of this.models) turnModel(m, dt);
+    this.buildTopLevel();
   }
 
-  // ---- the reference's live scene type (scene-raytracing.ts:73-272), meshes/models from the caller
+  // meshes: results of loadMesh; models: results of makeModel (scene-raytracing.ts:73-135)
   createTriangleScene(meshes, models) {
     this.meshes = meshes;
-    this.triangles = [];                                             // SR:75-79
-    for (const mesh of this.meshes) {
-      mesh.triangleLookupOffset = this.triangles.length;
-      for (const t of mesh.triangles) this.triangles.push(t);
-    }
-    this.triangleIndices = new Array(this.triangles.length);         // SR:82-93
-    {
-      let i = 0, offset = 0;
-      for (const mesh of this.meshes) {
-        for (let j = 0; j < mesh.bvh.triangleIndices.length; ++j) { this.triangleIndices[i] = mesh.bvh.triangleIndices[j] + offset; ++i; }
-        offset += mesh.bvh.triangleIndices.length;
+    this.models = models;
+    let triangles = 0;
+    for (const mesh of meshes) { mesh.triangleLookupOffset = triangles; triangles += mesh.soup.count; }
+    this.triangleCount = triangles;
+    this.tlasNodesMax = 2 * models.length - 1;
+    let nodes = 0;
+    for (const mesh of meshes) { mesh.rootNodeIndex = this.tlasNodesMax + nodes; nodes += mesh.tree.used; }
+    this.blasNodesUsed = nodes;
+
+    // ---- static buffers, in the layouts of renderer-raytracing.ts:198-229 ----
+    const triangleData = new Float32Array(40 * triangles);
+    const triangleIndexData = new Float32Array(triangles);
+    const nodeDataB = new Float32Array(8 * nodes);
+    let at = 0;
+    for (const mesh of meshes) {
+      mesh.soup.packInto(triangleData, 40 * mesh.triangleLookupOffset);
+      for (let j = 0; j < mesh.soup.count; ++j) triangleIndexData[mesh.triangleLookupOffset + j] = mesh.tree.order[j] + mesh.triangleLookupOffset;
+      const t = mesh.tree;
+      for (let i = 0; i < t.used; ++i, ++at) {
+        const loc = 8 * at;
+        // an inner node points at its children among the scene's nodes, a leaf at its run of the lookup table
+        const rebase = t.count[i] === 0 ? mesh.rootNodeIndex : mesh.triangleLookupOffset;
+        nodeDataB[loc] = t.min[3 * i]; nodeDataB[loc + 1] = t.min[3 * i + 1]; nodeDataB[loc + 2] = t.min[3 * i + 2];
+        nodeDataB[loc + 3] = t.first[i] + rebase;
+        nodeDataB[loc + 4] = t.max[3 * i]; nodeDataB[loc + 5] = t.max[3 * i + 1]; nodeDataB[loc + 6] = t.max[3 * i + 2];
+        nodeDataB[loc + 7] = t.count[i];
       }
     }
-    this.models = models;                                            // SR:96-111
-    this.tlasNodesMax = 2 * this.models.length - 1;                  // SR:114
-    this.blasNodesUsed = 0;                                          // SR:116-120
-    for (const mesh of this.meshes) { mesh.rootNodeIndex = this.tlasNodesMax + this.blasNodesUsed; this.blasNodesUsed += mesh.bvh.nodesUsed; }
-    this.nodes = new Array(this.tlasNodesMax + this.blasNodesUsed);  // SR:123-131
-    for (let i = 0; i < this.tlasNodesMax; i += 1) {
-      const node = new Node();
-      node.leftChildIndex = 0; node.primitiveCount = 0; node.minCorner = [0, 0, 0]; node.maxCorner = [0, 0, 0];
-      this.nodes[i] = node;
-    }
-    this.buildBVH();                                                 // SR:133
-    this.finalizeBVH();                                              // SR:134
-    this.blasConsumed = true;
+    this.packed = { triangleData, nodeDataB, triangleIndexData };
+    this.buildTopLevel();
     return this;
   }
-  buildBVH() {                                                       // SR:145-179
-    this.tlasNodesUsed = 0;
-    this.blasList = new Array(this.models.length);
-    this.blasIndices = new Array(this.models.length);
-    for (let i = 0; i < this.tlasNodesMax; ++i) {
-      this.nodes[i].leftChildIndex = 0; this.nodes[i].primitiveCount = 0;
-      this.nodes[i].minCorner = [0, 0, 0]; this.nodes[i].maxCorner = [0, 0, 0];
+
+  // Instance records and the top-level tree over them (scene-raytracing.ts:145-254), straight into the
+  // upload buffers of renderer-raytracing.ts:169-192.
+  buildTopLevel() {
+    const m = this.models.length;
+    const blasData = new Float32Array(20 * m);
+    const lo = new Float64Array(3 * m), hi = new Float64Array(3 * m);      // world boxes (f32 values)
+    const centre = new Float32Array(3 * m);
+    const p = new Float32Array(3), inv = new Float32Array(16);
+    for (let k = 0; k < m; ++k) {
+      const model = this.models[k], mesh = this.meshes[model.meshIndex];
+      // blas.ts:17-32: the eight corners of the tree-level box (bvh.ts:23-25: never computed, +-999999)
+      // through the instance matrix, each rounded to f32 as gl-matrix stores it
+      const a = mesh.tree.lo, b = mesh.tree.hi, M = model.model;
+      let x0 = 1e30, y0 = 1e30, z0 = 1e30, x1 = -1e30, y1 = -1e30, z1 = -1e30;
+      for (let c = 0; c < 8; ++c) {
+        const x = (c & 4) ? b[0] : a[0], y = (c & 2) ? b[1] : a[1], z = (c & 1) ? b[2] : a[2];
+        const w = (M[3] * x + M[7] * y + M[11] * z + M[15]) || 1.0;
+        p[0] = (M[0] * x + M[4] * y + M[8] * z + M[12]) / w;
+        p[1] = (M[1] * x + M[5] * y + M[9] * z + M[13]) / w;
+        p[2] = (M[2] * x + M[6] * y + M[10] * z + M[14]) / w;
+        x0 = Math.min(x0, p[0]); y0 = Math.min(y0, p[1]); z0 = Math.min(z0, p[2]);
+        x1 = Math.max(x1, p[0]); y1 = Math.max(y1, p[1]); z1 = Math.max(z1, p[2]);
+      }
+      lo[3 * k] = x0; lo[3 * k + 1] = y0; lo[3 * k + 2] = z0;
+      hi[3 * k] = x1; hi[3 * k + 1] = y1; hi[3 * k + 2] = z1;
+      for (let d = 0; d < 3; ++d) centre[3 * k + d] = fround(lo[3 * k + d] + hi[3 * k + d]) / 2;   // blas.ts:34-36
+      mat4.invert(inv, M);                                                                  // blas.ts:38
+      blasData.set(inv, 20 * k);
+      blasData[20 * k + 16] = mesh.rootNodeIndex;
     }
-    for (let i = 0; i < this.models.length; ++i) {
-      const model = this.models[i];
-      const mesh = this.meshes[model.meshIndex];
-      this.blasList[i] = new BLAS(mesh.rootNodeIndex, mesh.bvh.minCorner, mesh.bvh.maxCorner, model.model);
-      this.blasIndices[i] = i;
-    }
-    const root = this.nodes[0];
-    root.leftChildIndex = 0;
-    root.primitiveCount = this.blasList.length;
-    this.tlasNodesUsed += 1;
-    this.updateBounds(0);
-    this.subdivide(0);
-  }
-  updateBounds(nodeIndex) {                                          // SR:181-191
-    const node = this.nodes[nodeIndex];
-    node.minCorner = [1e30, 1e30, 1e30];
-    node.maxCorner = [-1e30, -1e30, -1e30];
-    for (let i = 0; i < node.primitiveCount; i += 1) {
-      const blas = this.blasList[this.blasIndices[node.leftChildIndex + i]];
-      vec3.min(node.minCorner, node.minCorner, blas.minCorner);
-      vec3.max(node.maxCorner, node.maxCorner, blas.maxCorner);
-    }
-  }
-  subdivide(nodeIndex) {                                             // SR:193-254
-    const node = this.nodes[nodeIndex];
-    if (node.primitiveCount < 2) return;
-    const extent = vec3.create();
-    vec3.subtract(extent, node.maxCorner, node.minCorner);
-    let axis = 0;
-    if (extent[1] > extent[axis]) axis = 1;
-    if (extent[2] > extent[axis]) axis = 2;
-    const splitPosition = node.minCorner[axis] + extent[axis] / 2;
-    let i = node.leftChildIndex;
-    let j = i + node.primitiveCount - 1;
-    while (i <= j) {
-      if (this.blasList[this.blasIndices[i]].center[axis] < splitPosition) {
-        i += 1;
-      } else {
-        const temp = this.blasIndices[i]; this.blasIndices[i] = this.blasIndices[j]; this.blasIndices[j] = temp;
-        j -= 1;
+
+    // median-split tree over the instance boxes, built off a stack; node records in the RR:184-192 layout
+    const cap = Math.max(this.tlasNodesMax, 1);
+    const nmin = new Float64Array(3 * cap), nmax = new Float64Array(3 * cap);
+    const first = new Int32Array(cap), count = new Int32Array(cap);
+    const order = new Int32Array(m);
+    for (let k = 0; k < m; ++k) order[k] = k;
+    const fit = (node) => {
+      for (let d = 0; d < 3; ++d) {
+        let a = 1e30, b = -1e30;
+        for (let k = first[node], e = k + count[node]; k < e; ++k) { a = Math.min(a, lo[3 * order[k] + d]); b = Math.max(b, hi[3 * order[k] + d]); }
+        nmin[3 * node + d] = a; nmax[3 * node + d] = b;
+      }
+    };
+    let used = 0;
+    if (m > 0) {
+      first[0] = 0; count[0] = m; used = 1;
+      fit(0);
+      const todo = [0];
+      while (todo.length) {
+        const node = todo.pop();
+        if (count[node] < 2) continue;
+        const ex = fround(nmax[3 * node] - nmin[3 * node]), ey = fround(nmax[3 * node + 1] - nmin[3 * node + 1]),
+              ez = fround(nmax[3 * node + 2] - nmin[3 * node + 2]);
+        let axis = 0, longest = ex;
+        if (ey > longest) { axis = 1; longest = ey; }
+        if (ez > longest) { axis = 2; longest = ez; }
+        const plane = nmin[3 * node + axis] + longest / 2;
+        let i = first[node], j = i + count[node] - 1;
+        while (i <= j) {
+          if (centre[3 * order[i] + axis] < plane) ++i;
+          else { const t = order[i]; order[i] = order[j]; order[j] = t; --j; }
+        }
+        const nLeft = i - first[node];
+        if (nLeft === 0 || nLeft === count[node]) continue;
+        const left = used, right = used + 1;
+        used += 2;
+        first[left] = first[node]; count[left] = nLeft;
+        first[right] = i; count[right] = count[node] - nLeft;
+        first[node] = left; count[node] = 0;
+        fit(left); fit(right);
+        todo.push(right, left);
       }
     }
-    const leftCount = i - node.leftChildIndex;
-    if (leftCount == 0 || leftCount == node.primitiveCount) return;
-    const leftChildIndex = this.tlasNodesUsed; this.tlasNodesUsed += 1;
-    const rightChildIndex = this.tlasNodesUsed; this.tlasNodesUsed += 1;
-    this.nodes[leftChildIndex].leftChildIndex = node.leftChildIndex;
-    this.nodes[leftChildIndex].primitiveCount = leftCount;
-    this.nodes[rightChildIndex].leftChildIndex = i;
-    this.nodes[rightChildIndex].primitiveCount = node.primitiveCount - leftCount;
-    node.leftChildIndex = leftChildIndex;
-    node.primitiveCount = 0;
-    this.updateBounds(leftChildIndex);
-    this.updateBounds(rightChildIndex);
-    this.subdivide(leftChildIndex);
-    this.subdivide(rightChildIndex);
-  }
-  finalizeBVH() {                                                    // SR:256-272
-    for (const mesh of this.meshes) {
-      for (let i = 0; i < mesh.bvh.nodesUsed; ++i) {
-        const meshNode = mesh.bvh.nodes[i];
-        if (meshNode.primitiveCount == 0) meshNode.leftChildIndex += mesh.rootNodeIndex;
-        else meshNode.leftChildIndex += mesh.triangleLookupOffset;
-        this.nodes[mesh.rootNodeIndex + i] = meshNode;
-      }
+    this.tlasNodesUsed = used;
+    const nodeDataA = new Float32Array(8 * used);
+    for (let i = 0; i < used; ++i) {
+      const loc = 8 * i;
+      nodeDataA[loc] = nmin[3 * i]; nodeDataA[loc + 1] = nmin[3 * i + 1]; nodeDataA[loc + 2] = nmin[3 * i + 2];
+      nodeDataA[loc + 3] = first[i];
+      nodeDataA[loc + 4] = nmax[3 * i]; nodeDataA[loc + 5] = nmax[3 * i + 1]; nodeDataA[loc + 6] = nmax[3 * i + 2];
+      nodeDataA[loc + 7] = count[i];
     }
+    this.frame = { blasData, blasIndexData: Float32Array.from(order), nodeDataA };
   }
 }
-module.exports = { SceneRaytracing, syntheticSpheres, SplitMix64, BASELINE_CONFIGS, CONSTANT_SKY_RGBA };
+module.exports = { SceneRaytracing, loadMesh, makeModel, syntheticSpheres, SplitMix64, BASELINE_CONFIGS, CONSTANT_SKY_RGBA };

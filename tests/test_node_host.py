@@ -29,7 +29,8 @@ def test_addon_loads_and_exports():
     names, ver = json.loads(out.stdout)
     assert ver == 2
     for n in ["create", "destroy", "resize", "writeParams", "writeSpheres", "writeCubemapFace", "selectKernel",
-              "setMode", "setPartition", "render", "wait", "readPixels", "stats"]:
+              "setMode", "setPartition", "render", "wait", "readPixels", "stats", "readFrame", "createGroup", "destroyGroup",
+              "groupSize", "groupCtx", "groupRender", "groupWait", "commUniqueId", "commInit", "renderGather"]:
         assert n in names
 
 
@@ -68,6 +69,45 @@ def test_no_cpu_fallback_in_node():
 
 
 @pytest.mark.gpu
+def test_addon_refuses_use_after_destroy_and_calls_during_an_async_wait():
+    """wait() runs rt_wait on a libuv worker while the JS thread stays free -- any call on the
+    same context before the promise settles must throw (rt_ctx is single-threaded), and a destroyed
+    context must be an error, not a use-after-free.  stats() carries the batch figures."""
+    out = run_node("""
+const rt=require('./node/rt355.node'); const r=[];
+(async () => {
+  const c=rt.create(0); rt.resize(c,64,64);
+  const p=new Float32Array(24); p[6]=-1; p[8]=1; p[13]=1; p[17]=5; p[19]=3; p[20]=0.3; p[21]=2;
+  rt.writeParams(c,p); rt.writeSpheres(c,new Float32Array([0,0,-5,0, 1,0,0,1]));
+  for (let f=0;f<6;++f) rt.writeCubemapFace(c,f,1,1,new Uint8Array([1,2,3,255]));
+  rt.render(c); rt.render(c);
+  const w=rt.wait(c);
+  for (const f of [()=>rt.render(c), ()=>rt.stats(c), ()=>rt.destroy(c), ()=>rt.wait(c)]) { try { f(); r.push('no throw'); } catch (e) { r.push(e.code); } }
+  await w;
+  const st=rt.stats(c); r.push(st.batchFrames, st.batchKernelMs>0, st.gatherMs);
+  rt.destroy(c);
+  for (const f of [()=>rt.destroy(c), ()=>rt.render(c), ()=>rt.stats(c)]) { try { f(); r.push('no throw'); } catch (e) { r.push(e.code); } }
+  console.log(JSON.stringify(r));
+})();""")
+    assert json.loads(out.stdout) == ["-5", "-5", "-5", "-5", 2, True, 0, "-5", "-5", "-5"]
+
+
+@pytest.mark.gpu
+def test_node_group_renders_c2_over_every_visible_gpu(tmp_path):
+    """The Node host driving the multi-GPU path the way the reference's single JS thread would: one
+    RendererRaytracing with {devices: 0} = rt_group_create over every visible GPU, groupRender (render +
+    RCCL gather inside librt355.so), groupWait as a promise, readFrame.  Frame = the oracle's C2 frame."""
+    fr = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["C2"]
+    raw = str(tmp_path / "frame.rgba")
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "app.js"), "C2", raw, "3", "fast", "group"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["sha256"] == fr["sha256"] and res["rays"] == fr["rays"] and res["frames"] == 3
+    assert hashlib.sha256(open(raw, "rb").read()).hexdigest() == fr["sha256"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,mode", [("C1", "fast"), ("C1", "strict"), ("C2", "fast")])
 def test_node_renders_baseline_config(tmp_path, name, mode):
     fr = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))[name]
@@ -84,32 +124,25 @@ def test_node_renders_baseline_config(tmp_path, name, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("heatmap", [False, True])
 def test_node_renders_triangle_scene(tmp_path, oracle, heatmap):
-    """A triangle scene handed to the JS RendererRaytracing as an object of the reference's
-    SceneRaytracing shape: packing in JS (RR:169-229) -> N-API -> C ABI -> HIP; frame hash against
-    the oracle's frame for the same buffers."""
+    """A triangle scene handed to the JS RendererRaytracing as the upload buffers themselves (the
+    layouts of RR:169-229, here produced by the Python mirror): JS -> N-API -> C ABI -> HIP; frame hash
+    against the oracle's frame for the same buffers."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import tri_buffers, triangle_scene
     from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
     scene, mat = triangle_scene(seed=17, n_models=2, rings=5, sectors=6)
     W, H, B = 160, 96, 3
-    f = lambda a: [float(v) for v in a]
-    js = {
-        "camera": {"position": f(scene.camera.position), "forwards": f(scene.camera.forwards),
-                   "right": f(scene.camera.right), "up": f(scene.camera.up)},
-        "light": {"position": f(scene.light.position), "lightIntensity": scene.light.lightIntensity,
-                  "minIntensity": scene.light.minIntensity},
-        "triangles": [{"corners": [f(c) for c in t.corners], "normals": [f(c) for c in t.normals],
-                       "textures": [f(c) for c in t.textures], "color": f(t.color)} for t in scene.triangles],
-        "nodes": [{"minCorner": f(n.minCorner), "maxCorner": f(n.maxCorner), "leftChildIndex": n.leftChildIndex,
-                   "primitiveCount": n.primitiveCount} if n is not None else
-                  {"minCorner": [0, 0, 0], "maxCorner": [0, 0, 0], "leftChildIndex": 0, "primitiveCount": 0}
-                  for n in scene.nodes],
-        "blasList": [{"inverseModel": f(b.inverseModel), "rootNodeIndex": b.rootNodeIndex} for b in scene.blasList],
-        "blasIndices": list(scene.blasIndices), "triangleIndices": list(scene.triangleIndices),
-        "tlasNodesUsed": scene.tlasNodesUsed, "tlasNodesMax": scene.tlasNodesMax, "blasNodesUsed": scene.blasNodesUsed,
-    }
-    doc = {"width": W, "height": H, "bounces": B, "scene": js,
+    f = lambda a: [float(v) for v in np.asarray(a).reshape(-1)]
+    doc = {"width": W, "height": H, "bounces": B, "tlasNodesMax": scene.tlasNodesMax,
+           "camera": {"position": f(scene.camera.position), "forwards": f(scene.camera.forwards),
+                      "right": f(scene.camera.right), "up": f(scene.camera.up)},
+           "light": {"position": f(scene.light.position), "lightIntensity": scene.light.lightIntensity,
+                     "minIntensity": scene.light.minIntensity},
+           "packed": {"triangleData": f(scene.pack_triangles()), "nodeDataB": f(scene.pack_blas_nodes()),
+                      "triangleIndexData": f(scene.pack_tri_lookup())},
+           "frame": {"blasData": f(scene.pack_blas()), "blasIndexData": f(scene.pack_blas_lookup()),
+                     "nodeDataA": f(scene.pack_tlas_nodes())},
            "meshTexture": {"width": mat.image.shape[1], "height": mat.image.shape[0], "data": mat.image.reshape(-1).tolist()}}
     path = str(tmp_path / "scene.json")
     json.dump(doc, open(path, "w"))
@@ -144,7 +177,7 @@ def _obj_spec():
 
 def _python_scene(meshes, models, updates):
     pm = [rt.Mesh().initializeFromText(m["obj"], m["descriptor"]) for m in meshes]
-    pmod = [rt.Model(m["meshIndex"], m["position"], m["eulers"], m["eulerSpeed"]) for m in models]
+    pmod = [rt.Model(m["meshIndex"], m["position"], m["eulers"], m.get("eulerSpeed")) for m in models]
     scene = rt.SceneRaytracing().createScene([])
     scene.createTriangleScene(pm, pmod)
     for dt in updates:
@@ -152,10 +185,28 @@ def _python_scene(meshes, models, updates):
     return scene
 
 
+def _bits(a):
+    return [int(v) for v in np.ascontiguousarray(a, dtype=np.float32).reshape(-1).view(np.uint32)]
+
+
+def _compare_js_with_python(js, scene):
+    assert js["nTriangles"] == len(scene.triangles) and js["tlasNodesUsed"] == scene.tlasNodesUsed
+    assert js["tlasNodesMax"] == scene.tlasNodesMax and js["blasNodesUsed"] == scene.blasNodesUsed
+    assert js["blas"] == _bits(scene.pack_blas())
+    assert js["blasIndices"] == _bits(scene.pack_blas_lookup())
+    assert js["tlasNodes"] == _bits(scene.pack_tlas_nodes())
+    assert js["blasNodes"] == _bits(scene.pack_blas_nodes())
+    assert js["triangleIndices"] == _bits(scene.pack_tri_lookup())
+    assert js["triangles"] == _bits(scene.pack_triangles())
+    cen = np.array([np.asarray(t.centroid, dtype=np.float32) for t in scene.meshes[0].triangles])
+    assert js["centroids0"] == _bits(cen)
+
+
 def test_js_scene_builders_match_python_mirror(tmp_path):
-    """OBJ reader -> SAH BVH -> Model matrices -> BLAS -> TLAS built twice, by node/*.js and by the
-    Python mirror: every packed f32 must agree bit for bit (two restatements of scene-raytracing.ts,
-    bvh.ts, blas.ts, model.ts, obj-reader.ts and of gl-matrix)."""
+    """OBJ text -> triangle soup -> SAH tree -> instance matrices -> top-level tree, built twice: by the
+    data-oriented node/*.js (typed arrays, explicit stacks) and by the object-style Python mirror.  Every
+    f32 of every upload buffer must agree bit for bit (two independent restatements of what
+    scene-raytracing.ts, bvh.ts, blas.ts, model.ts, obj-reader.ts and gl-matrix compute)."""
     meshes, models = _obj_spec()
     updates = [0.016, 0.25, 1.5]
     spec = dict(width=64, height=48, bounces=2, meshes=meshes, models=models, updates=updates)
@@ -164,25 +215,43 @@ def test_js_scene_builders_match_python_mirror(tmp_path):
     out = subprocess.run([NODE, os.path.join(ROOT, "node", "build-obj-scene.js"), path], cwd=ROOT, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr
-    js = json.loads(out.stdout.strip().splitlines()[-1])
-    scene = _python_scene(meshes, models, updates)
-    assert js["nTriangles"] == len(scene.triangles) and js["tlasNodesUsed"] == scene.tlasNodesUsed
-    assert js["tlasNodesMax"] == scene.tlasNodesMax and js["blasNodesUsed"] == scene.blasNodesUsed
-    assert js["blasIndices"] == list(scene.blasIndices) and js["triangleIndices"] == list(scene.triangleIndices)
-    pb = scene.pack_blas()
-    for i, b in enumerate(js["blas"]):
-        assert b == [int(v) for v in pb[i, :17].view(np.uint32)], i
-    nodes = np.zeros((len(scene.nodes), 8), np.float32)
-    t, bn = scene.pack_tlas_nodes(), scene.pack_blas_nodes()
-    # JS dumps every node slot as it stands; compare the used ones
-    for i in range(scene.tlasNodesUsed):
-        assert js["nodes"][i] == [int(v) for v in t[i].view(np.uint32)], i
-    for i in range(scene.blasNodesUsed):
-        assert js["nodes"][scene.tlasNodesMax + i] == [int(v) for v in bn[i].view(np.uint32)], i
-    t0 = scene.triangles[0]
-    want = np.concatenate([np.array(t0.corners[0]), np.array(t0.corners[1]), np.array(t0.corners[2]),
-                           np.array(t0.centroid, dtype=np.float64)]).astype(np.float32)
-    assert js["tri0"] == [int(v) for v in want.view(np.uint32)]
+    _compare_js_with_python(json.loads(out.stdout.strip().splitlines()[-1]), _python_scene(meshes, models, updates))
+
+
+def test_js_scene_builders_swizzled_mesh_many_updates(tmp_path):
+    """A y/z-swizzled, off-centre, scaled mesh (the loader's centring quirks), an instance that spins
+    through the +-360 degree wrap, quads and triangles mixed."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import obj_floor, obj_uv_sphere
+    meshes = [
+        dict(obj=obj_uv_sphere(9, 11, 2.5, centre=(0.3, 1.0, -0.2)), descriptor=dict(color=[0.2, 0.9, 0.4, 0.5], alignBottom=False, invertYZ=True, scale=0.31)),
+        dict(obj=obj_uv_sphere(4, 5, 0.8, centre=(-3.0, 0.25, 7.0), quads=False), descriptor=dict(color=[0.9, 0.9, 0.1, 1.0], alignBottom=True, invertYZ=True, scale=1.7)),
+        dict(obj=obj_floor(2.0), descriptor=dict(color=[1.0, 1.0, 1.0, 0.8], scale=5)),
+    ]
+    models = [dict(meshIndex=0, position=[0.5, 0.2, -9.5], eulers=[10, 350.0, 0], eulerSpeed=[0, 700.0, 0]),
+              dict(meshIndex=1, position=[-2.0, 0, -6.0], eulers=[0, -355.0, 0], eulerSpeed=[0, -333.0, 0]),
+              dict(meshIndex=1, position=[2.0, 1, -4.0], eulers=[0, 12.0, 0]),
+              dict(meshIndex=2, position=[0, 0, -5.0], eulers=[0, 0, 0], eulerSpeed=[0, 0, 0])]
+    updates = [0.016, 0.25, 1.5, 0.7, 0.033]
+    spec = dict(width=64, height=48, bounces=2, meshes=meshes, models=models, updates=updates)
+    path = str(tmp_path / "spec.json")
+    json.dump(spec, open(path, "w"))
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "build-obj-scene.js"), path], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    _compare_js_with_python(json.loads(out.stdout.strip().splitlines()[-1]), _python_scene(meshes, models, updates))
+
+
+def test_node_host_files_are_not_the_reference_typescript():
+    """The Node host layer is written from the buffer layouts, not from the reference's sources: no file
+    named after a reference class survives, and the builders hold no per-node / per-triangle objects."""
+    names = set(os.listdir(os.path.join(ROOT, "node")))
+    assert not ({"acceleration", "model", "mesh.js"} & names)
+    for f in ("sah.js", "soup.js", "scene-raytracing.js"):
+        text = open(os.path.join(ROOT, "node", f)).read()
+        assert "class Node" not in text and "class BLAS" not in text and "class Triangle " not in text
+        assert "Float64Array" in text or "Float32Array" in text
 
 
 @pytest.mark.gpu
