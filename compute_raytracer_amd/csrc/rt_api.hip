@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -15,6 +18,63 @@
 #include "rt_bvh_build.h"
 
 thread_local std::string g_rt_err;
+
+// Rebuilds the hierarchy's topology for moved spheres off the caller's thread.  rt_write_spheres with an
+// unchanged sphere count posts the new records here; frames meanwhile use the OLD topology with node
+// bounds refitted on the device (rt_bvh.hip: bvh_refit) -- always valid, only looser as spheres drift --
+// and the next frame that follows a sphere write after the worker has finished takes the new one.
+struct rt_rebuild {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false, pending = false, ready = false;
+    std::vector<float> in_records;            // job (latest posted wins)
+    uint32_t in_n = 0;
+    std::vector<float> out_rec;               // result
+    std::vector<uint32_t> out_link;
+    uint32_t out_n = 0, out_nodes = 0;
+
+    void run() {
+        std::vector<float> records, rec;
+        std::vector<uint32_t> link;
+        for (;;) {
+            uint32_t n;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || pending; });
+                if (stop) return;
+                records.swap(in_records);
+                n = in_n;
+                pending = false;
+            }
+            const uint32_t nodes = rt_bvh_build(records.data(), n, rec, link);
+            std::lock_guard<std::mutex> lk(m);
+            out_rec.swap(rec);
+            out_link.swap(link);
+            out_n = n;
+            out_nodes = nodes;
+            ready = true;
+        }
+    }
+    void post(const float* records, uint32_t n) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            in_records.assign(records, records + 8u * (size_t)n);
+            in_n = n;
+            pending = true;
+        }
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        cv.notify_one();
+    }
+    ~rt_rebuild() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+    }
+};
 
 namespace {
 
@@ -112,6 +172,8 @@ int rt_destroy(rt_ctx* c) {
     for (int k = 0; k < kStreams; ++k)
         if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
     rt_comm_release(c);
+    delete c->rebuild;
+    c->rebuild = nullptr;
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_scene);
     for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
@@ -251,6 +313,12 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
     c->n16 = (n + 15u) & ~15u;
     c->h_records.assign(records, records + 8u * (size_t)n);   // the hierarchy is built lazily from this copy
     c->bvh_valid = false;
+    // Moved spheres, same count: the next frame refits the node bounds on the device and keeps the topology;
+    // a new topology for these positions is built on the worker thread meanwhile (enqueue takes it when done).
+    if (n != 0 && n == c->bvh_topo_n) {
+        if (!c->rebuild) c->rebuild = new (std::nothrow) rt_rebuild();
+        if (c->rebuild) c->rebuild->post(records, n);
+    }
     c->scene_bound = (float)rt_scene_bound(records, n);   // scene extent, for the filter's validity range (enqueue)
     c->have_spheres = true;
     c->prep_spheres_valid = false;
@@ -409,10 +477,29 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     const bool need_bvh = use_bvh && !c->bvh_valid;
 
     if (queue_pipeline) { int rc = ensure_queue(c); if (rc != RT_OK) return rc; }
-    if (need_bvh) {   // host build; the device arrays may be reallocated: nothing may be in flight
+    // The hierarchy after rt_write_spheres.  A changed sphere count (or the first frame): host build, here and
+    // now.  The same count: the topology on the device stays, its node bounds are refitted there (below);
+    // a topology the worker thread has finished meanwhile is taken first.  Either way the device arrays may be
+    // rewritten or reallocated: nothing may be in flight (rt_write_spheres has drained already).
+    const bool refit = need_bvh && c->bvh_topo_n == c->n && c->bvh_topo_n != 0u;
+    bool upload_topology = false;
+    if (need_bvh) {
         int rc = drain(c);
         if (rc != RT_OK) return rc;
-        const uint32_t nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link);
+        uint32_t nodes = c->bvh_nodes;
+        if (!refit) {
+            nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link);
+            upload_topology = true;
+        } else if (c->rebuild) {
+            std::lock_guard<std::mutex> lk(c->rebuild->m);
+            if (c->rebuild->ready && c->rebuild->out_n == c->n) {
+                c->h_bvh_rec.swap(c->rebuild->out_rec);
+                c->h_bvh_link.swap(c->rebuild->out_link);
+                nodes = c->rebuild->out_nodes;
+                upload_topology = true;
+            }
+            c->rebuild->ready = false;
+        }
         if (nodes + 1u > c->bvh_cap) {
             (void)hipFree(c->d_bvh_rec); (void)hipFree(c->d_bvh_link);
             c->d_bvh_rec = nullptr; c->d_bvh_link = nullptr; c->bvh_cap = 0;
@@ -465,10 +552,15 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         c->prep_params_valid = true;
     }
     if (need_bvh) {
-        const size_t nn = (size_t)c->bvh_nodes + 1u;
-        RT_HIP(hipMemcpyAsync(c->d_bvh_rec, c->h_bvh_rec.data(), nn * sizeof(float4), hipMemcpyHostToDevice, s));
-        RT_HIP(hipMemcpyAsync(c->d_bvh_link, c->h_bvh_link.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        RT_HIP(hipStreamSynchronize(s));   // pageable sources: the vectors may be rebuilt later
+        if (upload_topology) {
+            const size_t nn = (size_t)c->bvh_nodes + 1u;
+            RT_HIP(hipMemcpyAsync(c->d_bvh_rec, c->h_bvh_rec.data(), nn * sizeof(float4), hipMemcpyHostToDevice, s));
+            RT_HIP(hipMemcpyAsync(c->d_bvh_link, c->h_bvh_link.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            RT_HIP(hipStreamSynchronize(s));   // pageable sources: the vectors may be rebuilt later
+            c->bvh_topo_n = c->n;
+        }
+        // bounds of the inner nodes for the current positions (a topology from the worker was built for older ones)
+        if (refit) RT_HIP(rt_launch_bvh_refit(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, c->d_records, s));
         RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, fa.geo_f, s));
         c->bvh_valid = true;
     }

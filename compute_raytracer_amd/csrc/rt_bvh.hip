@@ -81,6 +81,95 @@ __global__ void bvh_fill_leaves(float4* rec, const uint32_t* link, uint32_t n_no
     if (l & 0x80000000u) rec[i] = geo_f[l & 0x7FFFFFFFu];
 }
 
+// ---- device: node bounds for moved spheres (same topology) ----------------------------------------------
+// The hierarchy's TOPOLOGY -- which spheres a node covers: the links and leaf ids -- stays valid when
+// spheres move; only the bounding spheres of the inner nodes must follow.  The reference rebuilds its
+// top-level structure every frame (scene-raytracing.ts:138-143); here a frame that follows
+// rt_write_spheres with an unchanged sphere count refits the inner nodes on the device -- one wave per
+// node, the members (the leaves between the node and its skip link) spread over the lanes -- while the
+// host rebuilds the topology for the new positions on a worker thread and hands it over when it is
+// done (rt_api.hip: rt_rebuild).  Same construction as rt_bvh_build.h: centre of the members' box,
+// shrink-wrapped (the centre walks towards the farthest member while the radius falls), stored in f32,
+// radius taken about the STORED centre, times 1.04 (the slack the node test's proof needs, see the header),
+// all in f64.  A node bound that contains its members is all exactness asks for.
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bvh_refit(float4* __restrict__ rec, const uint32_t* __restrict__ link,
+                                                  uint32_t n_nodes, const float* __restrict__ records) {
+    const uint32_t node = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (node >= n_nodes) return;
+    const uint32_t lk = link[node];
+    if (lk & 0x80000000u) return;                       // leaves are filled from the filter records (bvh_fill_leaves)
+    const uint32_t first = node + 1u, end = lk >> 2;     // the subtree: nodes (node, end)
+    auto sphere = [&](uint32_t j, double c[3], double& r) -> bool {     // member j of this lane's stride, if it is a leaf
+        if (j >= end) return false;
+        const uint32_t l = link[j];
+        if (!(l & 0x80000000u)) return false;
+        const float* s = records + 8u * (size_t)(l & 0x7FFFFFFFu);
+        for (int a = 0; a < 3; ++a) { const double v = (double)s[a]; c[a] = v == v ? v : 0.0; }   // NaN orders as 0 (host build)
+        const double rv = fabs((double)s[7]);
+        r = rv == rv ? rv : 0.0;
+        return true;
+    };
+    // radius about P (and which member is farthest), over all members
+    auto radius_at = [&](const double P[3], double far[3]) -> double {
+        double best = -1.0, bc[3] = {0.0, 0.0, 0.0};
+        for (uint32_t j = first + lane; j < end; j += 64u) {
+            double c[3], r;
+            if (!sphere(j, c, r)) continue;
+            const double dx = c[0] - P[0], dy = c[1] - P[1], dz = c[2] - P[2];
+            const double d = sqrt(dx * dx + dy * dy + dz * dz) + r;
+            if (d > best) { best = d; bc[0] = c[0]; bc[1] = c[1]; bc[2] = c[2]; }
+        }
+        const double R = wave_max_f64(best);
+        // the farthest member's centre: the lowest lane that holds the maximum speaks
+        const uint64_t who = __ballot(best == R);
+        const int src = who ? (int)__builtin_ctzll(who) : 0;
+        for (int a = 0; a < 3; ++a) far[a] = __shfl(bc[a], src, 64);
+        return R;
+    };
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t j = first + lane; j < end; j += 64u) {
+        double c[3], r;
+        if (!sphere(j, c, r)) continue;
+        for (int a = 0; a < 3; ++a) { mn[a] = fmin(mn[a], c[a] - r); mx[a] = fmax(mx[a], c[a] + r); }
+    }
+    double P[3];
+    for (int a = 0; a < 3; ++a) P[a] = 0.5 * (wave_min_f64(mn[a]) + wave_max_f64(mx[a]));
+    double far[3];
+    double Rp = radius_at(P, far);
+    for (int it = 0; it < 32; ++it) {                   // wave-uniform: every quantity below is
+        const double sx = far[0] - P[0], sy = far[1] - P[1], sz = far[2] - P[2];
+        const double len = sqrt(sx * sx + sy * sy + sz * sz);
+        if (!(len > 1e-12)) break;
+        const double Q[3] = {P[0] + sx / len * 0.05 * Rp, P[1] + sy / len * 0.05 * Rp, P[2] + sz / len * 0.05 * Rp};
+        double farq[3];
+        const double Rq = radius_at(Q, farq);
+        if (!(Rq < Rp)) break;
+        P[0] = Q[0]; P[1] = Q[1]; P[2] = Q[2]; Rp = Rq;
+        far[0] = farq[0]; far[1] = farq[1]; far[2] = farq[2];
+    }
+    const float C[3] = {(float)P[0], (float)P[1], (float)P[2]};     // the record stores the centre in f32:
+    const double Cd[3] = {(double)C[0], (double)C[1], (double)C[2]};   // the radius is taken about THAT point
+    double unused[3];
+    double R = radius_at(Cd, unused);
+    R *= 1.04;
+    const double c2 = Cd[0] * Cd[0] + Cd[1] * Cd[1] + Cd[2] * Cd[2];
+    const double k = c2 * (1.0 - (double)RT_FILTER_EPS) - R * R * (1.0 + (double)RT_FILTER_KAPPA);
+    if (lane == 0)
+        rec[node] = make_float4(C[0] * RT_FILTER_SCALE, C[1] * RT_FILTER_SCALE, C[2] * RT_FILTER_SCALE,
+                                (float)(k * (double)RT_FILTER_SCALE2));
+}
+
 #ifdef RT_BVH_COUNT
 #define g_steps steps_acc
 #endif
@@ -402,6 +491,12 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
 
 hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     return a.signed_filter ? rtk::launch_bvh<true>(a, s) : rtk::launch_bvh<false>(a, s);
+}
+
+hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    hipLaunchKernelGGL(rtk::bvh_refit, dim3((n_nodes + 3u) / 4u), dim3(256), 0, s, rec, link, n_nodes, records);
+    return hipGetLastError();
 }
 
 hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s) {

@@ -70,7 +70,9 @@ struct rt_ctx {
     float4* d_bvh_rec = nullptr;
     uint32_t* d_bvh_link = nullptr;
     uint32_t bvh_cap = 0, bvh_nodes = 0;
-    bool bvh_valid = false;              // built for the current spheres
+    bool bvh_valid = false;              // the device records bound the current spheres
+    uint32_t bvh_topo_n = 0;             // sphere count the device topology (links, leaf ids) was built for; 0: none
+    struct rt_rebuild* rebuild = nullptr;   // worker thread that rebuilds the topology for moved spheres (rt_api.hip)
     uint8_t* d_face[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t fw[6] = {0, 0, 0, 0, 0, 0}, fh[6] = {0, 0, 0, 0, 0, 0};
     uint32_t face_texel0[6] = {0, 0, 0, 0, 0, 0};   // first texel (rgb) of each face: a one-texel sky of one colour is "flat"
