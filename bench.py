@@ -50,6 +50,10 @@ FLOP_PER_TEST = 25          # WGSL-literal count of HK:308-311
 PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)" = 1024 SIMDs x 64 flop/clk x 2.4 GHz
 FLOP_SLOTS_PER_VALU = 128   # one wave64 VALU instruction = 2 cycles of a SIMD-32 = 2 x 32 lanes x 2 flop
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+PEAK_L2_GBPS = 34500.0      # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+# The reference's live scene type (triangles behind a two-level BVH, RK:168-410) on a procedural scene of the
+# reference scene's size (12.8 k triangles, 3 instances + floor): the window of the reference's screenshot and 4K
+TRI_CONFIGS = {"TRI": dict(width=1344, height=846, bounces=4), "TRI4K": dict(width=3840, height=2160, bounces=4)}
 FLIGHT = 4                  # frames the library keeps concurrent (rt_ctx rotates over 4 streams / buffer sets)
 
 
@@ -106,6 +110,41 @@ def cpu_baseline(cfg, scene, sky, target_s):
     }
 
 
+def cpu_baseline_tri(cfg, scene, mat, sky, target_s, gpu_frame):
+    """The triangle path of the oracle on every `step`-th tile; also the work counters (node / triangle /
+    instance gathers per ray) the GPU kernel's gather roofline is priced with, and a check of the GPU frame's
+    sampled rows against the oracle's."""
+    import numpy as np
+    from oracle import rt_oracle_py as orc
+    from compute_raytracer_amd.procedural import tri_buffers
+    W, H, B = cfg["width"], cfg["height"], cfg["bounces"]
+    p, b = scene.pack_params(B), tri_buffers(scene, mat)
+    threads = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0)), 16))
+    ntiles = (H + 7) // 8
+    step0 = max(1, ntiles // 4)
+    t0 = time.perf_counter()
+    orc.render_tri(p, b, sky.faces, W, H, tile_first=step0 // 2, tile_step=step0, threads=threads)
+    per_tile = (time.perf_counter() - t0) / max(len(range(step0 // 2, ntiles, step0)), 1)
+    want = max(1, min(ntiles, int(target_s / max(per_tile, 1e-9))))
+    step = max(1, ntiles // want)
+    orc.tri_counters()
+    t0 = time.perf_counter()
+    img, _, rays = orc.render_tri(p, b, sky.faces, W, H, tile_first=step // 2, tile_step=step, threads=threads)
+    dt = time.perf_counter() - t0
+    nodes, tests, blas = orc.tri_counters()
+    rows = [y for y in range(H) if (y // 8) >= step // 2 and ((y // 8) - step // 2) % step == 0]
+    n = len(range(step // 2, ntiles, step))
+    return {
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": "oracle/rt_oracle.c triangle path (scalar fp32 C, OpenMP over rows) on %d of %d 8-row tiles (every %d-th) "
+                  "of the same %dx%d / %d-triangle / %d-bounce frame: %d rays in %.1f s" % (n, ntiles, step, W, H, len(scene.triangles), B, rays, dt),
+        "fps_equiv": (n / ntiles) / dt,
+        "gather_bytes_per_ray": (32.0 * nodes + 160.0 * tests + 80.0 * blas) / max(rays, 1),
+        "per_ray": {"node_loads_32B": nodes / max(rays, 1), "triangle_tests_160B": tests / max(rays, 1), "instance_records_80B": blas / max(rays, 1)},
+        "gpu_rows_match": bool(np.array_equal(gpu_frame[rows], img[rows])) if gpu_frame is not None else None,
+    }
+
+
 def kernel_label(mode, variant, N):
     hierarchy = mode == "fast" and (variant == 4 or (variant == 0 and N >= 128))
     queue_pipeline = mode == "fast" and not hierarchy and (variant in (2, 3) or (variant in (0, 4, 5) and N >= 320))
@@ -155,11 +194,19 @@ def main():
         dist.init_process_group("gloo")              # control plane; the pixels travel over RCCL inside librt355.so
 
     name = a.config or ("C3" if world == 1 else "C4")
-    if name not in rt.BASELINE_CONFIGS:
+    tri = name in TRI_CONFIGS
+    if not tri and name not in rt.BASELINE_CONFIGS:
         sys.exit("bench.py: unknown config %s" % name)
-    cfg = rt.BASELINE_CONFIGS[name]
+    mat = None
+    if tri:
+        from compute_raytracer_amd.procedural import triangle_scene
+        cfg = dict(TRI_CONFIGS[name], spheres=0, seed=21, skybox=None)
+        scene, mat = triangle_scene(seed=21, n_models=2, rings=48, sectors=64)     # 12,846 triangles, ~10 s of host build
+    else:
+        cfg = rt.BASELINE_CONFIGS[name]
     W, H, N, B = cfg["width"], cfg["height"], cfg["spheres"], cfg["bounces"]
-    scene = rt.synthetic_scene(N, cfg["seed"])
+    if not tri:
+        scene = rt.synthetic_scene(N, cfg["seed"])
     if cfg["skybox"]:
         png = os.path.join(ROOT, "assets", "daylight-skybox.png")    # the reference's asset, if the user supplies it
         sky = rt.CubemapMaterial.from_png(png) if os.path.exists(png) else rt.CubemapMaterial.synthetic_daylight()
@@ -167,7 +214,7 @@ def main():
         sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
 
     r = rt.RendererRaytracing(W, H, scene, device=local_rank, maxBounces=B)
-    r.initialize(sky)
+    r.initialize(sky, mat)
     r.set_mode(a.mode == "strict")
     r.set_variant(a.variant)
     root = 0 if a.gather == "root" else -1
@@ -228,7 +275,8 @@ def main():
 
     # the last timed frame, hashed against the oracle's frame of this config
     check = None
-    gold = golden_frame(name)
+    gold = None if tri else golden_frame(name)
+    tri_frame = r.read_pixels() if tri and not multi and rank == 0 else None
     if gold is not None and (not multi or rank == 0 or root < 0):
         frame = r.read_frame() if multi else r.read_pixels()
         check = {"sha256_matches_oracle_frame": hashlib.sha256(frame.tobytes()).hexdigest() == gold["sha256"],
@@ -268,6 +316,8 @@ def main():
         ms_per_step = elapsed / a.steps * 1e3
         value = rays_frame * a.steps / elapsed / 1e6
         label, hierarchy, queue_pipeline = kernel_label(a.mode, a.variant, N)
+        if tri:
+            label, hierarchy, queue_pipeline = "trace_triangles<4> (TLAS/BLAS traversal, pixel per lane)", False, False
         # launches of consecutive frames overlap on the device (each on a share of the chip): the chip-level
         # rate is work per launch / frame period; one frame at a time: / the launch duration.  The two-kernel
         # brute-force pipeline shares a path queue: its frames are serialised by the library.
@@ -276,6 +326,8 @@ def main():
         flops_alg = FLOP_PER_TEST * N * rays_kernel
         local_rows = tiles.tiles_of_rank(H, 0, world) * 8
         hbm_bytes = 4 * W * min(local_rows, H) + 32 * N + 96
+        if tri:     # image store + the scene read once: 160-B triangles, 32-B nodes, 80-B instance records, two f32 lookups
+            hbm_bytes = 4 * W * min(local_rows, H) + 164 * len(scene.triangles) + 32 * len(scene.nodes) + 84 * len(scene.models) + 96
         hbm_gbps = hbm_bytes / (roof_ms * 1e-3) / 1e9
 
         # executed work of the dominant kernel, from the committed PMC summary (tools/pmc_summary.py)
@@ -319,14 +371,39 @@ def main():
         roof["hbm"] = {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
                        "bytes_per_launch": hbm_bytes}
         alg_tf = flops_alg / (roof_ms * 1e-3) / 1e12
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline_tri(cfg, scene, mat, sky, a.cpu_seconds, tri_frame) if tri else cpu_baseline(cfg, scene, sky, a.cpu_seconds)
+        if tri:
+            # The triangle kernel is a pointer chase: per ray it gathers 32-B nodes, 160-B triangles and 80-B instance
+            # records (counted by the oracle on the sampled tiles, same frame).  The scene (2.9 MB) lives in L2, so
+            # the gathers are priced against the L2 roof; the VALU view stays in `valu` when a PMC pass exists.
+            valu_view = {k: roof.get(k) for k in ("achieved", "frac", "valu_wave_insts_per_launch", "from_profile", "serial") if k in roof}
+            roof = {"bound": "l2-gather", "kernel": label, "peak": PEAK_L2_GBPS, "unit": "GB/s", "kernel_ms_avg": kernel_ms,
+                    "time_ms": roof_ms, "launches_in_flight": FLIGHT if overlapping else 1, "traffic": (prof or {}).get("hbm_bytes_per_launch"),
+                    "valu": valu_view, "hbm": roof["hbm"]}
+            if cpu is not None:
+                gbytes = cpu["gather_bytes_per_ray"] * rays_kernel
+                ach = gbytes / (roof_ms * 1e-3) / 1e9
+                roof.update({"achieved": ach, "frac": ach / PEAK_L2_GBPS, "gather_bytes_per_launch": gbytes,
+                             "gathers_per_ray": cpu["per_ray"],
+                             "basis": "achieved = (32 B x node loads + 160 B x triangle tests + 80 B x instance records) per ray, counted by "
+                                      "the oracle on the sampled tiles of this frame, x rays per launch / time_ms; peak = aggregate L2 bandwidth"})
+            else:
+                roof.update({"achieved": None, "frac": None, "basis": "gather counts come from the cpu_baseline leg (--no-cpu-baseline given)"})
+            check = {"sampled_tiles_match_oracle": cpu["gpu_rows_match"]} if cpu is not None else None
         out = {
-            "metric": "Mrays/s at %dx%d, %d spheres, %d bounces" % (W, H, N, B),
+            "metric": ("Mrays/s at %dx%d, %d triangles, %d bounces" % (W, H, len(scene.triangles), B)) if tri else
+                      ("Mrays/s at %dx%d, %d spheres, %d bounces" % (W, H, N, B)),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "frames_per_s": 1e3 / ms_per_step,
             "serial_ms_per_step": serial_ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d, %d spheres (seed %d), %d bounces, %s, reference default camera/light"
+            "config": {"workload": ("%s: %dx%d, procedural triangle scene of the reference scene's size (%d triangles, %d instances, "
+                                    "%d nodes; seed %d), %d bounces, constant sky, reference default camera/light"
+                                    % (name, W, H, len(scene.triangles), len(scene.models), len(scene.nodes), cfg["seed"], B)) if tri else
+                                   "%s: %dx%d, %d spheres (seed %d), %d bounces, %s, reference default camera/light"
                                    % (name, W, H, N, cfg["seed"], B, "6x512^2 procedural sky cube" if cfg["skybox"] else "constant sky"),
                        "mode": a.mode, "variant": a.variant, "rays_per_frame": rays_frame,
                        "frames_in_flight": 1 if a.serial else FLIGHT,
@@ -334,7 +411,7 @@ def main():
                                                            " + RCCL %s inside librt355 (rt_render_gather)" %
                                                            ("gather to rank 0" if root == 0 else "all-gather"))},
             "roofline": roof,
-            "algorithmic_speedup_vs_bruteforce": {
+            "algorithmic_speedup_vs_bruteforce": None if tri else {
                 "value": alg_tf / PEAK_FP32_TFLOPS, "algorithmic_tflops": alg_tf, "flop_per_launch": flops_alg,
                 "note": "25 flop x N spheres x rays per launch / time_ms against the fp32 vector peak: how much faster the frame "
                         "is produced than a kernel that really examined every (ray, sphere) pair could at that peak"},
@@ -342,8 +419,8 @@ def main():
         }
         if multi:
             out["gather_ms_avg"] = gather_ms
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, scene, sky, a.cpu_seconds)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
     r.close()

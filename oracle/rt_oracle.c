@@ -73,6 +73,7 @@ typedef struct {
 } oscene;
 
 static render_state trace_tlas(const rt_oracle_tri_scene* T, v3 o, v3 d, uint32_t* steps);
+static void tri_work_flush(void);
 static v3 tex2d_sample(const rt_oracle_face* f, float u, float v);
 
 /* ---- HK:307-331 hitSphere ------------------------------------------------ */
@@ -468,6 +469,7 @@ static int render_scene(const float params[24], const oscene* S,
             shade_pixel(&sc, S, faces, W, H, x, y, rgb, &rays);
             size_t idx = (size_t)y * W + x;
             if (out_rays_px) out_rays_px[idx] = (uint16_t)(rays - before);
+            if (x + 1u == W) tri_work_flush();
             if (out_rgb) {
                 out_rgb[3 * idx + 0] = rgb[0];
                 out_rgb[3 * idx + 1] = rgb[1];
@@ -506,8 +508,25 @@ static inline uint32_t sclamp(uint32_t i) { return i > STACK_SIZE - 1u ? STACK_S
 
 typedef struct { v3 minCorner; float leftChildIndex; v3 maxCorner; float primitiveCount; } bvh_node;
 
+/* Work counters of the triangle path (measurement only: bench.py prices the GPU kernel's gathers with
+ * them): 32-B node loads, 160-B triangle tests, 80-B instance records read.  Per thread, folded into
+ * the totals row by row; rt_oracle_tri_counters reads and clears the totals. */
+static __thread uint64_t tl_tri_work[3];
+static uint64_t g_tri_work[3];
+static void tri_work_flush(void) {
+    for (int k = 0; k < 3; ++k) {
+        if (tl_tri_work[k]) __atomic_fetch_add(&g_tri_work[k], tl_tri_work[k], __ATOMIC_RELAXED);
+        tl_tri_work[k] = 0;
+    }
+}
+void rt_oracle_tri_counters(uint64_t out[3]) {
+    tri_work_flush();
+    for (int k = 0; k < 3; ++k) out[k] = __atomic_exchange_n(&g_tri_work[k], 0, __ATOMIC_RELAXED);
+}
+
 static inline bvh_node load_node(const rt_oracle_tri_scene* T, uint32_t i) {
     bvh_node n;
+    tl_tri_work[0] += 1;
     if (i >= T->n_nodes) {       /* robust buffer access: out-of-range loads read the last element */
         i = T->n_nodes - 1u;
     }
@@ -575,6 +594,7 @@ static inline render_state hit_triangle(v3 o, v3 d, const float* tri, float tMin
 static render_state trace_blas(const rt_oracle_tri_scene* T, v3 o, v3 d, const float* blas,
                                float nearestHit, const render_state* renderState, uint32_t* steps) {
     const float* m = blas;   /* m[4*c + r] */
+    tl_tri_work[2] += 1;
     /* mat4x4 * vec4: sum over columns, left to right (RK:254-255) */
     v3 oo = V(((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.0f,
               ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.0f,
@@ -622,6 +642,7 @@ static render_state trace_blas(const rt_oracle_tri_scene* T, v3 o, v3 d, const f
                 if (ti >= T->n_triangles) ti = T->n_triangles - 1u;
                 render_state ns = hit_triangle(oo, od, T->triangles + 40u * (size_t)ti, 0.001f,
                                                blasNearestHit, &brs);            /* RK:312-316 */
+                tl_tri_work[1] += 1;
                 if (steps) *steps += 1;                                          /* HK:279 */
                 if (ns.hit) { blasNearestHit = ns.t; brs = ns; }                 /* RK:318-321 */
             }

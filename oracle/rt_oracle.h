@@ -127,6 +127,10 @@ int rt_oracle_heatmap_tri(const float params[24], const rt_oracle_tri_scene* tri
 int rt_oracle_trace_tri_rays(const rt_oracle_tri_scene* tri, uint32_t n, const float* origins,
                              const float* dirs, float* out_t, int32_t* out_tri);
 
+/* Work the triangle path did since the last call (all threads): out[0] 32-B node loads, out[1] 160-B
+ * triangle tests, out[2] 80-B instance records.  Reading clears.  Measurement only (bench.py --config TRI). */
+void rt_oracle_tri_counters(uint64_t out[3]);
+
 int rt_oracle_max_threads(void);
 
 #ifdef __cplusplus

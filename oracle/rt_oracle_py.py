@@ -213,6 +213,16 @@ def heatmap_tri(params, buffers, W, H, threads=0):
     return out, steps
 
 
+def tri_counters():
+    """(node loads, triangle tests, instance records) of the triangle path since the last call; clears."""
+    out = (ctypes.c_uint64 * 3)()
+    L = lib()
+    L.rt_oracle_tri_counters.restype = None
+    L.rt_oracle_tri_counters.argtypes = [ctypes.c_void_p]
+    L.rt_oracle_tri_counters(out)
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 def trace_tri_rays(buffers, origins, dirs):
     """Nearest-hit t (or -1) of arbitrary rays against a triangle scene (RK:168-244)."""
     t, keep = _tri_scene(buffers)

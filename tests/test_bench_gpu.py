@@ -91,3 +91,18 @@ def test_bench_serial_mode_times_single_launches():
     assert abs(r["time_ms"] - r["kernel_ms_avg"]) < 1e-9
     assert r["kernel_ms_avg"] <= d["ms_per_step"] * 1.05          # a launch is the bulk of a serial step
     assert abs(d["serial_ms_per_step"] - d["ms_per_step"]) < 1e-9
+
+
+def test_bench_triangle_config_prices_gathers_against_l2():
+    """the reference's live scene type gets the same evidence as the sphere kernel:
+    `--config TRI` (12.8 k procedural triangles, the reference screenshot's window, 4 bounces) with a
+    bytes-based roofline (32-B node + 160-B triangle + 80-B instance gathers per ray, counted by the
+    oracle on the sampled tiles, against the L2 roof) and the GPU's sampled rows checked against the oracle."""
+    d, _ = run_bench("--steps", "6", "--warmup", "2", "--config", "TRI", "--cpu-seconds", "4")
+    assert "triangles" in d["metric"] and d["config"]["rays_per_frame"] > 1344 * 846
+    r = d["roofline"]
+    assert r["bound"] == "l2-gather" and r["unit"] == "GB/s" and r["peak"] == 34500.0
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["gathers_per_ray"]["node_loads_32B"] > 5 and r["gathers_per_ray"]["triangle_tests_160B"] > 0.5
+    assert d["frame_check"]["sampled_tiles_match_oracle"] is True
+    assert d["cpu_baseline"]["kind"] == "port" and "triangle path" in d["cpu_baseline"]["sample"]

@@ -75,3 +75,54 @@ def test_assemble_round_trip_single_process():
             g[r, j, y & 7] = frame[y]
         assert np.array_equal(tiles.assemble_numpy(g, W, H, world), frame)
         assert np.array_equal(tiles.assemble_torch(torch.from_numpy(g.reshape(-1)), W, H, world).numpy(), frame)
+
+
+def _control_plane_worker(rank, world, port, W, H, result_dir):
+    """What bench.py does around the C-ABI calls when N > 1, with gloo standing in for RCCL: rank 0's
+    128-byte communicator id reaches every rank (rt_comm_unique_id -> rt_comm_init), the tiles go to the
+    ROOT only (rt_render_gather(root 0): grouped ncclSend / ncclRecv = a gather), the root de-interleaves,
+    and the timings are reduced with MAX / the ray counts with SUM."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import rt_oracle_py as orc
+        ids = [bytes(range(128)) if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ok = ids[0] == bytes(range(128)) and len(ids[0]) == 128
+        scene = rt.synthetic_scene(9, 99)
+        sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+        p, s = scene.pack_params(2), scene.pack_spheres()
+        part, _, rays = orc.render(p, s, sky.faces, W, H, tile_first=rank, tile_step=world, threads=1)
+        pt = tiles.padded_tiles(H, world)
+        local = np.zeros((pt, 8, W, 4), np.uint8)
+        for j in range(tiles.tiles_of_rank(H, rank, world)):
+            y0 = (rank + j * world) * 8
+            rows = min(8, H - y0)
+            local[j, :rows] = part[y0:y0 + rows]
+        mine = torch.from_numpy(local.reshape(-1))
+        slots = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, slots, dst=0)                       # rank r's message lands in slot r of the root's buffer
+        if rank == 0:
+            frame = tiles.assemble_numpy(torch.cat(slots).numpy(), W, H, world)
+            full, _, full_rays = orc.render(p, s, sky.faces, W, H, threads=1)
+            ok = ok and np.array_equal(frame, full)
+        t = torch.tensor([0.5 + rank, float(rays)], dtype=torch.float64)
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        ok = ok and float(tmax[0]) == 0.5 + (world - 1)
+        if rank == 0:
+            ok = ok and int(round(float(tsum[1]))) == full_rays
+        dist.barrier()
+        open(os.path.join(result_dir, "rank%d" % rank), "w").write("ok" if ok else "MISMATCH")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 32, 53), (3, 24, 40)])
+def test_bench_control_plane_and_gather_to_root(tmp_path, world, W, H):
+    port = _free_port()
+    mp.spawn(_control_plane_worker, args=(world, port, W, H, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"
