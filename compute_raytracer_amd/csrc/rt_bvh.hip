@@ -73,6 +73,22 @@
 
 namespace rtk {
 
+// LDS layout of a workgroup with the nodes staged (NLDS): the x/255 table first, then the links at byte
+// address l0, the records at byte address 4 * l0 -- so that a record's address is its link's address
+// shifted left by two, no base to add in the walk --, then the candidate lists.  l0 is the smallest
+// 16-byte multiple >= 1024 (the table) whose quadruple clears the end of the link array.
+__host__ __device__ inline uint32_t bvh_lds_l0(uint32_t n_nodes, uint32_t base) {
+    // 4 * (base + l0) >= base + l0 + 4 * (n + 1)   <=>   3 * (base + l0) >= 4 * (n + 1)
+    uint32_t l0 = 1024u;
+    const uint32_t need = (4u * (n_nodes + 1u) + 2u) / 3u;
+    if (base + l0 < need) l0 = need - base;
+    return (l0 + 15u) & ~15u;
+}
+__host__ __device__ inline uint32_t bvh_lds_lists(uint32_t n_nodes, uint32_t base) {   // byte offset of the lists
+    const uint32_t l0 = bvh_lds_l0(n_nodes, base);
+    return 4u * (base + l0) - base + 16u * ((n_nodes + 4u) & ~3u);
+}
+
 // ---- device: leaf records = the filter records prep_spheres wrote ------------------------------------
 __global__ void bvh_fill_leaves(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,18 +255,19 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     // arithmetic, the record's address is one v_lshl_add, and the links themselves are stored in
     // this unit.  Node n is a sentinel that never passes and links to itself: a lane that is done
     // (or has no ray) idles on it without an exec-mask test per step; the wave leaves the loop
-    // when every lane sits there.  Two steps per trip halve the loop overhead.
+    // when every lane sits there.  Four steps per trip: the loop's own compares and branches are not
+    // free on a pipe that is priced per opcode (C3 with frames in flight: 2, 3, 4 steps per trip = 2.22,
+    // 2.13, 2.12 ms).
     typedef __attribute__((address_space(3))) const uint32_t* lds_u32;
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const f4v* lds_f4;
     const uint32_t l0 = NLDS ? (uint32_t)(uintptr_t)L : 0u;                       // LDS address of L[0]
-    const uint32_t r0 = NLDS ? (uint32_t)(uintptr_t)R - 4u * l0 : 0u;             // record address = 4 * j + r0
     auto step = [&](uint32_t j) -> uint32_t {
         uint32_t lk;
         float4 g;
         if (NLDS) {
             lk = *(lds_u32)(uintptr_t)j;
-            const f4v gv = *(lds_f4)(uintptr_t)(4u * j + r0);
+            const f4v gv = *(lds_f4)(uintptr_t)(4u * j);          // bvh_lds_l0: the records sit at 4 x the links' address
             g = make_float4(gv.x, gv.y, gv.z, gv.w);
         } else {
             lk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(L) + j);
@@ -283,7 +300,9 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
         if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
 #endif
         j = step(j);
-        if (__ballot(cnt >= (uint32_t)(CAP - 1)) != 0ull) drain();
+        j = step(j);
+        j = step(j);
+        if (__ballot(cnt >= (uint32_t)(CAP - 3)) != 0ull) drain();       // room for the four entries of the next trip
     }
     drain();
     i = (j - l0) >> 2;
@@ -300,9 +319,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
     const uint32_t n4 = (n + 4u) & ~3u;
-    uint32_t* sL = reinterpret_cast<uint32_t*>(lds);                 // links at LDS offset 0 (see trace_bvh)
-    float4* sR = lds + (NLDS ? n4 / 4u : 0u);
-    uint32_t* lists = reinterpret_cast<uint32_t*>(sR + (NLDS ? n4 : 0u));
+    // NLDS: [x/255 table | links at l0 | records at 4 * (address of the links) | lists]   (bvh_lds_l0)
+    char* const lds_b = reinterpret_cast<char*>(lds);
+    const uint32_t base = (uint32_t)(uintptr_t)lds;
+    const uint32_t l0off = bvh_lds_l0(n, base);
+    uint32_t* sL = reinterpret_cast<uint32_t*>(lds_b + (NLDS ? l0off : 0u));
+    float4* sR = reinterpret_cast<float4*>(lds_b + (NLDS ? 4u * (base + l0off) - base : 0u));
+    uint32_t* lists = reinterpret_cast<uint32_t*>(lds_b + (NLDS ? bvh_lds_lists(n, base) : 1024u));
+    (void)n4;
+    if (NLDS && base != 0u) return;      // the host sized the allocation for dynamic LDS at address 0 (no static LDS in this kernel)
     if (NLDS)
         for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) {
             sR[i] = A.bvh_rec[i];
@@ -315,7 +340,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     uint32_t* slot = lists + wave * (uint32_t)(CAP * 64) + lane;
     // rgba8unorm -> float table for the cube map texels: the reference's x / 255 division done
     // 256 times per workgroup instead of 12 times per sample
-    float* lut = reinterpret_cast<float*>(lists + WAVES * CAP * 64);
+    float* lut = reinterpret_cast<float*>(lds_b);                          // the first KiB
     for (uint32_t i = threadIdx.x; i < 256u; i += 64 * WAVES) lut[i] = (float)i / 255.0f;
     __syncthreads();
 
@@ -478,13 +503,13 @@ template <bool SGN>
 hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
     constexpr int CAP = 8;
-    const size_t n4 = ((size_t)a.bvh_nodes + 4u) & ~(size_t)3u;
-    const size_t nodes = n4 * 20u;
+    // dynamic LDS starts at address 0 of the workgroup's allocation (the kernels declare no static LDS);
+    // the kernel re-derives the layout from the address it actually gets
+    const size_t nodes = (size_t)bvh_lds_lists(a.bvh_nodes, 0u);        // table + links + records (+ the gap the 4x rule leaves)
     const size_t cap = 160u * 1024u;
-    constexpr size_t lut = 1024u;
-    if (nodes + 8u * CAP * 256u + lut <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * CAP * 256u + lut, s);
-    if (nodes + 16u * CAP * 256u + lut <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * CAP * 256u + lut, s);
-    return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 8u * CAP * 256u + lut, s);
+    if (nodes + 8u * CAP * 256u <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * CAP * 256u, s);
+    if (nodes + 16u * CAP * 256u <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * CAP * 256u, s);
+    return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * CAP * 256u, s);
 }
 
 }  // namespace rtk
