@@ -104,12 +104,24 @@ double rt_scene_bound(const float* records, uint32_t n) {
 // sign-aware filter is valid only while the rounding of h.oc (<= 7.3e-7 |oc|, |oc| <= 2*reach) stays
 // below half of the 0.001 a valid hit needs (rt_filter.h: filter_one); beyond 2^20 (or NaN / inf) the
 // 2^40-scaled filter arithmetic could overflow, and the frame is rendered by the literal kernel.
-void rt_plan(double scene_bound, const float* p, bool& filter_ok, uint32_t& signed_filter) {
+// smallest non-zero |radius| (+inf if there is none): the sign-aware forms rescale the test by 2^-124, which
+// must not push the quantities that decide it into the denormals; with every radius 0 or >= 2^-30 the
+// filter's margins (>= 2^-16 r^2) stay 40 binary orders above the smallest normal number
+double rt_scene_min_radius(const float* records, uint32_t n) {
+    double mn = INFINITY;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double r = std::fabs((double)records[8u * (size_t)i + 7u]);
+        if (r > 0.0 && r < mn) mn = r;
+    }
+    return mn;
+}
+
+void rt_plan(double scene_bound, double min_radius, const float* p, bool& filter_ok, uint32_t& signed_filter) {
     const double cam = std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
     const double lgt = std::sqrt((double)p[16] * p[16] + (double)p[17] * p[17] + (double)p[18] * p[18]);
     const double reach = rt_reach(scene_bound, cam, lgt);
     filter_ok = reach == reach && reach < 1048576.0;
-    signed_filter = (filter_ok && 2.0 * reach * 7.3e-7 < 5.0e-4) ? 1u : 0u;
+    signed_filter = (filter_ok && 2.0 * reach * 7.3e-7 < 5.0e-4 && min_radius >= 9.313225746154785e-10) ? 1u : 0u;   // 2^-30
 }
 
 }  // namespace
@@ -320,6 +332,7 @@ int rt_write_spheres(rt_ctx* c, const float* records, uint32_t n) {
         if (c->rebuild) c->rebuild->post(records, n);
     }
     c->scene_bound = (float)rt_scene_bound(records, n);   // scene extent, for the filter's validity range (enqueue)
+    c->scene_min_radius = rt_scene_min_radius(records, n);
     c->have_spheres = true;
     c->prep_spheres_valid = false;
     return RT_OK;
@@ -457,7 +470,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     // ---- which kernels render this frame ----
     bool filter_ok = false;
     uint32_t signed_filter = 0;
-    rt_plan(c->scene_bound, c->params, filter_ok, signed_filter);
+    rt_plan(c->scene_bound, c->scene_min_radius, c->params, filter_ok, signed_filter);
     // Fast mode renders through the bounding-sphere hierarchy (rt_bvh.hip) from 128 spheres on
     // (default, variant 0; measured crossover against the brute-force kernels ~100 spheres) or
     // whenever variant 4 asks for it; variant 5 is the brute-force default, 1-3 its forms.
@@ -746,7 +759,7 @@ int rt_filter_plan(const float* records, uint32_t n, const float params[24], int
     if ((n && !records) || !params || !filter_ok || !signed_filter) return fail(RT_ERR_INVALID_ARG, "rt_filter_plan: NULL argument");
     bool ok = false;
     uint32_t sgn = 0;
-    rt_plan((double)(float)rt_scene_bound(records, n), params, ok, sgn);
+    rt_plan((double)(float)rt_scene_bound(records, n), rt_scene_min_radius(records, n), params, ok, sgn);
     *filter_ok = ok ? 1 : 0;
     *signed_filter = (int)sgn;
     return RT_OK;

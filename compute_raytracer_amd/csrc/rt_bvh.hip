@@ -233,6 +233,17 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     const v3 m = V(-2.0f * os.x, -2.0f * os.y, -2.0f * os.z);
     const float p = dot(h, os);
     const float q = dot(os, os) * (1.0f - RT_FILTER_EPS);
+    // Sign-aware test on LDS nodes: min(b, 0) comes free as the `clamp` of the FMA that completes -b,
+    // once everything is rescaled so that |b| < 1: -b * 2^-62 (|b| < 2^61 inside the filter's validity
+    // range), and with it the squared quantities * 2^-124 -- powers of two, so every mantissa, hence every
+    // decision, is the one of the unscaled test (the staged records carry w * 2^-124, see the kernel).
+    // (v_min_f32 costs about two FMAs on this pipe.)
+    constexpr bool CLAMPED = SGN && NLDS;
+    constexpr float kT = 2.168404344971009e-19f;            // 2^-62
+    constexpr float kT2 = 4.70197740328915e-38f;            // 2^-124
+    const v3 hs = V(h.x * kT, h.y * kT, h.z * kT);
+    const v3 ms = V(m.x * kT2, m.y * kT2, m.z * kT2);
+    const float ps = -p * kT, qs = q * kT2;
     uint32_t cnt = 0;                    // entries in this lane's candidate column
 
     auto drain = [&]() {
@@ -273,10 +284,19 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
             lk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(L) + j);
             g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R) + 4u * (size_t)j);
         }
-        const float b = fnma_vvv(h.z, g.z, fnma_vvv(h.y, g.y, fnma_vvv(h.x, g.x, p)));
-        const float cp = fma_vvv(m.z, g.z, fma_vvv(m.y, g.y, fma_vvv(m.x, g.x, g.w)));
-        const float bm = SGN ? min0(b) : b;
-        const bool pass = __builtin_fmaf(bm, bm, -q) > cp;
+        bool pass;
+        if (CLAMPED) {
+            float nb;      // max(-b, 0) * 2^-62
+            const float part = fma_vvv(hs.y, g.y, fma_vvv(hs.x, g.x, ps));
+            asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nb) : "v"(hs.z), "v"(g.z), "v"(part));
+            const float cp = fma_vvv(ms.z, g.z, fma_vvv(ms.y, g.y, fma_vvv(ms.x, g.x, g.w)));
+            pass = __builtin_fmaf(nb, nb, -qs) > cp;
+        } else {
+            const float b = fnma_vvv(h.z, g.z, fnma_vvv(h.y, g.y, fnma_vvv(h.x, g.x, p)));
+            const float cp = fma_vvv(m.z, g.z, fma_vvv(m.y, g.y, fma_vvv(m.x, g.x, g.w)));
+            const float bm = SGN ? min0(b) : b;
+            pass = __builtin_fmaf(bm, bm, -q) > cp;
+        }
         const bool leaf = (int)lk < 0;
         if (leaf && pass) {
             slot[cnt * 64u] = lk;
@@ -330,7 +350,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     if (NLDS && base != 0u) return;      // the host sized the allocation for dynamic LDS at address 0 (no static LDS in this kernel)
     if (NLDS)
         for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) {
-            sR[i] = A.bvh_rec[i];
+            float4 r = A.bvh_rec[i];
+            if (SGN) r.w *= 4.70197740328915e-38f;      // 2^-124: the clamped form of the node test (trace_bvh)
+            sR[i] = r;
             const uint32_t lk = A.bvh_link[i];      // inner links become LDS addresses of the target's link
             sL[i] = (int)lk < 0 ? lk : lk + (uint32_t)(uintptr_t)sL;
         }

@@ -62,6 +62,7 @@ struct rt_ctx {
     float4* d_scene = nullptr;           // 8 float4 arrays of n16: geo lgt cam col geo_f lgt_f cam_f + {geo_w,lgt_w,cam_w,-}
     uint32_t n16 = 0;                    // n rounded up to a multiple of 16
     float scene_bound = 0.0f;            // max over spheres of |center| + radius (host side)
+    double scene_min_radius = 0.0;       // smallest non-zero |radius| (rt_plan: the rescaled sign-aware test)
     // bounding-sphere hierarchy (rt_bvh.hip): host copy of the records it is built from, the
     // build result and its device copy
     std::vector<float> h_records;

@@ -252,8 +252,9 @@ int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* 
 /* Which filter forms a frame of this scene may use (no device needed): *filter_ok = 0 when
  * max(|center| + |radius| over the spheres, |cameraPos|, |lightPosition|) is NaN, infinite or
  * >= 2^20 -- fast mode then renders the frame with the literal kernel --, *signed_filter = 1 when
- * that reach is below 342 (the sign-aware filter and hierarchy walk).  A NaN in ANY record, whatever
- * its position, switches both off. */
+ * that reach is below 342 and no sphere has a radius in (0, 2^-30) (the sign-aware filter and hierarchy
+ * walk; the walk's rescaled node test needs the second condition).  A NaN in ANY record, whatever its
+ * position, switches both off. */
 int rt_filter_plan(const float* records, uint32_t n, const float params[24], int* filter_ok, int* signed_filter);
 
 #ifdef __cplusplus

@@ -120,3 +120,7 @@ def test_filter_plan_nan_and_inf_are_sticky_wherever_the_record_sits():
     q = p.copy(); q[17] = np.inf
     assert _plan(base, q) == (0, 0)                 # light at infinity
     assert _plan(base[:0], p) == (1, 1)             # empty scene
+    s = base.copy(); s[3, 7] = 0.0
+    assert _plan(s, p) == (1, 1)                    # a zero radius is fine (nothing to rescale) ...
+    s[4, 7] = 1e-10
+    assert _plan(s, p) == (1, 0)                    # ... a radius in (0, 2^-30) keeps the filter but not its sign-aware, rescaled form

@@ -264,3 +264,31 @@ def test_random_call_sequences_with_frames_in_flight(seed):
     for i, k in pending.items():
         assert np.array_equal(bufs[i].cpu().numpy().reshape(H, W, 4), ref[k]), (seed, "final", i, k)
     r.close()
+
+
+@pytest.mark.parametrize("case", ["tiny_radii_in_a_normal_scene", "zero_radii", "millimetre_scene"])
+def test_rescaled_node_test_and_its_guard(oracle, case):
+    """The sign-aware walk rescales its node test by 2^-124 (min(b, 0) as the clamp of an FMA).  Radii in
+    (0, 2^-30) would push the deciding quantities towards the denormals: such scenes keep the filter but
+    take its unsigned, unscaled form (rt_filter_plan); zero radii need no guard; a scene a thousand times
+    smaller than the BASELINE ones still sits far inside the normal range."""
+    spheres = synthetic_spheres(400, 31)
+    scene = rt.SceneRaytracing().createScene(spheres)
+    if case == "tiny_radii_in_a_normal_scene":
+        for k in range(5, 400, 7):
+            spheres[k].radius = 1e-10 * (1 + k % 3)
+    elif case == "zero_radii":
+        for k in range(5, 400, 7):
+            spheres[k].radius = 0.0
+    else:
+        s = 1e-3
+        for sp in spheres:
+            sp.center = (np.asarray(sp.center, np.float64) * s).astype(np.float32)
+            sp.radius *= s
+        scene.camera.position = [float(v) * s for v in scene.camera.position]
+        scene.camera.update()
+        scene.light.position = [float(v) * s for v in scene.light.position]
+    ref, _, rays = oracle_render(oracle, scene, 128, 80, 6)
+    img, st = gpu_render(scene, 128, 80, 6, strict=False, variant=BVH)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays
