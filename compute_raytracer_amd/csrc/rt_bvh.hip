@@ -244,9 +244,13 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     const v3 hs = V(h.x * kT, h.y * kT, h.z * kT);
     const v3 ms = V(m.x * kT2, m.y * kT2, m.z * kT2);
     const float ps = -p * kT, qs = q * kT2;
-    uint32_t cnt = 0;                    // entries in this lane's candidate column
+    // this lane's candidate column in LDS: entries 256 bytes apart; wa = LDS address of the next free one
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32_w;
+    const uint32_t wa0 = (uint32_t)(uintptr_t)slot;
+    uint32_t wa = wa0;
 
     auto drain = [&]() {
+        const uint32_t cnt = (wa - wa0) >> 8;
         for (uint32_t k = 0; __ballot(k < cnt) != 0ull; ++k) {
 #ifdef RT_BVH_COUNT
             if (RT_BVH_COUNT == 4) g_steps += (threadIdx.x & 63u) == 0u ? 1u : 0u;     // drain iterations (wave)
@@ -258,7 +262,7 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
                 exact_any_order(V(g.x, g.y, g.z), g.w, si, o, d, fa, ta, nearest, idx);
             }
         }
-        cnt = 0;
+        wa = wa0;
     };
 
     // The walk's state is j = 4 * node index (+ the LDS address of the link array when the nodes
@@ -299,8 +303,8 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
         }
         const bool leaf = (int)lk < 0;
         if (leaf && pass) {
-            slot[cnt * 64u] = lk;
-            ++cnt;
+            *(lds_u32_w)(uintptr_t)wa = lk;
+            wa += 256u;
         }
         return (leaf || pass) ? j + 4u : lk;     // staged links already carry the LDS base
     };
@@ -322,7 +326,7 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
         j = step(j);
         j = step(j);
         j = step(j);
-        if (__ballot(cnt >= (uint32_t)(CAP - 3)) != 0ull) drain();       // room for the four entries of the next trip
+        if (__ballot(wa >= wa0 + 256u * (uint32_t)(CAP - 3)) != 0ull) drain();      // room for the four entries of the next trip
     }
     drain();
     i = (j - l0) >> 2;

@@ -106,6 +106,21 @@ __device__ inline v3 cube_tap(const RtFrameArgs& A, int face, int n, int i, int 
 // not pay for it in the BASELINE configs C1-C4), 2 = compiled for a textured sky only.
 template <int SKY = 0>
 __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = nullptr) {
+    if (SKY == 1) {
+        // Flat sky, compiled in: every face is the same single texel c, so the face does not matter, and the
+        // sample c + (wu * 0 + wv * 0) is c unless a weight is NaN.  wu = u - floor(u) is finite whenever
+        // sc / ma is (|sc| <= ma rules out infinities), so the NaN-ness of the weights is that of the two
+        // quotients: c + ((sc / ma) * 0 + (tc / ma) * 0) has the general path's value for every direction --
+        // with the major axis found by three compares and no face table, texel address or floor.
+        const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
+        float sc, tc, ma;
+        if (az >= ax && az >= ay) { sc = r.x; tc = r.y; ma = az; }
+        else if (ay >= ax)        { sc = r.x; tc = r.z; ma = ay; }
+        else                      { sc = r.z; tc = r.y; ma = ax; }
+        const v3 c = texel(A.face[0], 1, 1, 0, 0, lut);
+        const float z = (sc / ma) * 0.0f + (tc / ma) * 0.0f;      // signs of sc, tc do not matter: +-0 or NaN
+        return V(c.x + z, c.y + z, c.z + z);
+    }
     const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
     int face; float sc, tc, ma;
     if (az >= ax && az >= ay) {
