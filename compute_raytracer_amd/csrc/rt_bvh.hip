@@ -218,15 +218,13 @@ __device__ __forceinline__ void exact_any_order(v3 center, float r2, int s, v3 o
 // wave's slowest rays no longer holds 64 lanes for a handful.
 template <bool SGN, bool NLDS, int CAP, int TAIL>
 __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
-                                          const float4* __restrict__ geo, uint32_t* slot, uint32_t& i, v3 o, v3 d,
-                                          float& nearest, int& idx
+                                          const float4* __restrict__ geo, uint32_t* slot, unsigned long long* best,
+                                          uint32_t& i, v3 o, v3 d, float& nearest, int& idx
 #ifdef RT_BVH_COUNT
                                           , uint32_t& steps_acc
 #endif
                                           ) {
     const float a = dot(d, d);           // HK:308
-    const float fa = 4.0f * a;           // the (4*a) of HK:311
-    const float ta = 2.0f * a;           // HK:317
     const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_BVH_KAPPA);
     const v3 h = V(d.x * inv, d.y * inv, d.z * inv);
     const v3 os = V(o.x * RT_FILTER_SCALE, o.y * RT_FILTER_SCALE, o.z * RT_FILTER_SCALE);   // exact
@@ -249,19 +247,58 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     const uint32_t wa0 = (uint32_t)(uintptr_t)slot;
     uint32_t wa = wa0;
 
+    // Literal evaluation of the wave's candidates, POOLED.  Candidate lists are ragged -- 2.6 entries per ray
+    // on average, 6-9 in the longest list of a wave --, so evaluating "entry k of every lane" keeps under a
+    // third of the lanes busy (C3: 6.3 M wave-iterations of ~63 instructions per frame for 118 M candidates,
+    // a fifth of all VALU work).  Instead the wave compacts its lists into one pool in place (entry k of all
+    // lanes, k = 0, 1, ...: positions from a ballot and mbcnt), every lane takes pool items i, i + 64, ...,
+    // fetches the OWNER's ray with ds_bpermute, runs the reference's literal test (HK:308-318) and folds the
+    // result into the owner's slot of `best` with an LDS 64-bit atomic min on (t bits, sphere index) -- the
+    // lexicographic minimum the in-order `t < nearest` loop of the reference keeps (t > 0, so its bit
+    // pattern orders like its value; "no hit yet" is index 0xFFFFFFFF, which loses every tie).
     auto drain = [&]() {
+        const uint32_t lane = threadIdx.x & 63u;
         const uint32_t cnt = (wa - wa0) >> 8;
-        for (uint32_t k = 0; __ballot(k < cnt) != 0ull; ++k) {
+        uint32_t* const pool = slot - lane;                              // this wave's list area, as a linear array
+        uint32_t total = 0;                                              // wave-uniform
+        for (uint32_t k = 0;; ++k) {
+            const uint64_t m = __ballot(k < cnt);
+            if (m == 0ull) break;
+            uint32_t e = 0;
+            if (k < cnt) e = slot[k * 64u];                              // every lane reads row k before any lane writes
+            const uint32_t pos = total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (k < cnt) pool[pos] = (lane << 24) | (e & 0x00FFFFFFu);   // pos < 64 (k + 1): rows > k are untouched
+            total += (uint32_t)__popcll(m);
+        }
+        best[lane] = ((unsigned long long)__float_as_uint(nearest) << 32) | (unsigned long long)(uint32_t)idx;
+        for (uint32_t i = lane; __ballot(i < total) != 0ull; i += 64u) {
 #ifdef RT_BVH_COUNT
-            if (RT_BVH_COUNT == 4) g_steps += (threadIdx.x & 63u) == 0u ? 1u : 0u;     // drain iterations (wave)
-            if (RT_BVH_COUNT == 5) g_steps += k < cnt ? 1u : 0u;                       // candidates evaluated (lane)
+            if (RT_BVH_COUNT == 4) g_steps += lane == 0u ? 1u : 0u;                    // drain iterations (wave)
+            if (RT_BVH_COUNT == 5) g_steps += i < total ? 1u : 0u;                     // candidates evaluated (lane)
 #endif
-            if (k < cnt) {
-                const int si = (int)(slot[k * 64u] & 0x7FFFFFFFu);
+            const uint32_t e = i < total ? pool[i] : (lane << 24);
+            const int owner = (int)(e >> 24);
+            const int si = (int)(e & 0x00FFFFFFu);
+            const v3 oo = V(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+            const v3 od = V(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+            if (i < total) {
                 const float4 g = geo[si];
-                exact_any_order(V(g.x, g.y, g.z), g.w, si, o, d, fa, ta, nearest, idx);
+                const float a2 = dot(od, od);                     // HK:308
+                const v3 oc = sub(oo, V(g.x, g.y, g.z));
+                const float b = 2.0f * dot(od, oc);               // HK:309
+                const float c = dot(oc, oc) - g.w;                // HK:310
+                const float disc = b * b - (4.0f * a2) * c;       // HK:311
+                if (disc > 0.0f && b < 0.0f) {                    // HK:316; b >= 0 gives t <= 0
+                    const float t = (-b - sqrtf(disc)) / (2.0f * a2);   // HK:317
+                    if (t > 0.001f && t < 9999.0f)                // HK:318 with tMin / the initial tMax of RK:315, RK:172
+                        atomicMin(&best[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)si);
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const unsigned long long r = best[lane];
+        nearest = __uint_as_float((uint32_t)(r >> 32));
+        idx = (int)(uint32_t)r;
         wa = wa0;
     };
 
@@ -364,6 +401,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     const uint32_t* L = NLDS ? sL : A.bvh_link;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* slot = lists + wave * (uint32_t)(CAP * 64) + lane;
+    // per wave: 64 x (t bits, sphere index), the running nearest hits of the pooled literal evaluation (trace_bvh: drain)
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(lists + WAVES * CAP * 64) + wave * 64u;
     // rgba8unorm -> float table for the cube map texels: the reference's x / 255 division done
     // 256 times per workgroup instead of 12 times per sample
     float* lut = reinterpret_cast<float*>(lds_b);                          // the first KiB
@@ -447,10 +486,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
         const bool walking = node != n;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
-        trace_bvh<SGN, NLDS, CAP, TAIL>(R, L, n, A.geo, slot, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
+        trace_bvh<SGN, NLDS, CAP, TAIL>(R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
         if (walking && node == n) {
 #else
-        trace_bvh<SGN, NLDS, CAP, TAIL>(R, L, n, A.geo, slot, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
+        trace_bvh<SGN, NLDS, CAP, TAIL>(R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
         if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
 #endif
@@ -533,9 +572,13 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     // the kernel re-derives the layout from the address it actually gets
     const size_t nodes = (size_t)bvh_lds_lists(a.bvh_nodes, 0u);        // table + links + records (+ the gap the 4x rule leaves)
     const size_t cap = 160u * 1024u;
-    if (nodes + 8u * CAP * 256u <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * CAP * 256u, s);
-    if (nodes + 16u * CAP * 256u <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * CAP * 256u, s);
-    return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * CAP * 256u, s);
+    // per wave: CAP x 64 candidate entries + 64 eight-byte slots of running nearest hits.  Scenes whose nodes
+    // leave room for one 16-wave workgroup only (C5: 128 KB of nodes) get six-entry lists: 2 KB per wave again.
+    constexpr size_t per_wave = (size_t)CAP * 256u + 512u, per_wave6 = 6u * 256u + 512u;
+    if (nodes + 8u * per_wave <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * per_wave, s);
+    if (nodes + 16u * per_wave <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave, s);
+    if (nodes + 16u * per_wave6 <= cap)    return launch_bvh_as<16, SGN, true, 6, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave6, s);
+    return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * per_wave, s);
 }
 
 }  // namespace rtk
