@@ -339,6 +339,11 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
             pass = __builtin_fmaf(bm, bm, -q) > cp;
         }
         const bool leaf = (int)lk < 0;
+#ifdef RT_BVH_COUNT
+        if (RT_BVH_COUNT == 6) g_steps += leaf ? 1u : 0u;                              // leaf tests (lane)
+        if (RT_BVH_COUNT == 7) g_steps += (!leaf && pass) ? 1u : 0u;                   // inner nodes passed (lane)
+        if (RT_BVH_COUNT == 8) g_steps += (!leaf && lk != j) ? 1u : 0u;                // inner nodes tested (lane; the sentinel links to itself)
+#endif
         if (leaf && pass) {
             *(lds_u32_w)(uintptr_t)wa = lk;
             wa += 256u;
