@@ -51,6 +51,7 @@
 // oracle (tests/test_bvh_gpu.py: golden frames, random scenes over five orders of magnitude).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "rt_filter.h"
@@ -66,6 +67,9 @@
 #endif
 #ifndef RT_BVH_TAIL_SMALL
 #define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres) */
+#endif
+#ifndef RT_BVH_TAIL_SERIAL
+#define RT_BVH_TAIL_SERIAL 12  /* ... when one frame has the chip to itself */
 #endif
 #ifndef RT_BVH_TAIL_LARGE
 #define RT_BVH_TAIL_LARGE 32   /* 16-wave workgroups and the global-memory form */
@@ -216,8 +220,8 @@ __device__ __forceinline__ void exact_any_order(v3 center, float r2, int s, v3 o
 // completed and fewer than TAIL lanes are still walking, the call returns; the stragglers resume
 // in the next call, next to the fresh rays of the lanes that completed -- the long tail of a
 // wave's slowest rays no longer holds 64 lanes for a handful.
-template <bool SGN, bool NLDS, int CAP, int TAIL>
-__device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
+template <bool SGN, bool NLDS, int CAP>
+__device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
                                           const float4* __restrict__ geo, uint32_t* slot, unsigned long long* best,
                                           uint32_t& i, v3 o, v3 d, float& nearest, int& idx
 #ifdef RT_BVH_COUNT
@@ -356,7 +360,7 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
     for (;;) {
         const uint64_t walking = __ballot(j != jn);
         if (walking == 0ull) break;
-        if (TAIL > 0 && walking != walking0 && __builtin_popcount((uint32_t)walking) + __builtin_popcount((uint32_t)(walking >> 32)) < TAIL) break;
+        if (walking != walking0 && (uint32_t)(__builtin_popcount((uint32_t)walking) + __builtin_popcount((uint32_t)(walking >> 32))) < tail) break;
 #ifdef RT_BVH_COUNT   // development statistics: 1 = wave iterations, 2 = lane tests (reported as "rays")
         if (RT_BVH_COUNT == 1) g_steps += (threadIdx.x & 63u) == 0u ? 2u : 0u;
         if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
@@ -380,7 +384,7 @@ __device__ __forceinline__ void trace_bvh(const float4* __restrict__ R, const ui
 // chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
 // workgroups serve scenes whose nodes leave room for one workgroup per CU only (4 waves per SIMD).
 // FLAT: compiled for a one-colour 1x1 sky (A.sky_flat; C1-C4) -- no cube filtering code in the kernel.
-template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL, bool FLAT>
+template <int WAVES, bool SGN, bool NLDS, int CAP, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
@@ -491,10 +495,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
         const bool walking = node != n;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
-        trace_bvh<SGN, NLDS, CAP, TAIL>(R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
+        trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
         if (walking && node == n) {
 #else
-        trace_bvh<SGN, NLDS, CAP, TAIL>(R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
+        trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
         if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
 #endif
@@ -543,8 +547,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
 }
 
 template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
-hipError_t launch_bvh_as(const RtFrameArgs& a, size_t lds, hipStream_t s) {
-    auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, TAIL, true> : bvh_pixels<WAVES, SGN, NLDS, CAP, TAIL, false>;
+hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
+    // The walk is left for the shading pass once fewer than `tail` lanes still walk.  A frame that has the
+    // chip to itself prefers a lower threshold than frames that share it (C3: 12 vs 16 -- 2.40 -> 2.3x ms one
+    // frame at a time, but 2.08 -> 2.11 in flight): with one frame the end-of-frame tail is paid in full, and
+    // shorter trips shorten it.
+    RtFrameArgs a = a0;
+    a.bvh_tail = (uint32_t)TAIL;
+    if (TAIL == RT_BVH_TAIL_SMALL && a.grid_share <= 1u) a.bvh_tail = RT_BVH_TAIL_SERIAL;
+#ifdef RT_BVH_DEV_ENV
+    if (const char* e = getenv("RT355_BVH_TAIL")) a.bvh_tail = (uint32_t)atoi(e);
+#endif
+    auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, true> : bvh_pixels<WAVES, SGN, NLDS, CAP, false>;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
