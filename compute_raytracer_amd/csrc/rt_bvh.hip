@@ -68,9 +68,6 @@
 #ifndef RT_BVH_TAIL_SMALL
 #define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres) */
 #endif
-#ifndef RT_BVH_MIGRATE
-#define RT_BVH_MIGRATE 0       /* thin waves merge once the frame's pixels are handed out (bvh_pixels) */
-#endif
 #ifndef RT_BVH_TAIL_SERIAL
 #define RT_BVH_TAIL_SERIAL 12  /* ... when one frame has the chip to itself */
 #endif
@@ -383,9 +380,6 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
 }
 
 // ---- kernel ---------------------------------------------------------------------------------------------
-constexpr uint32_t kBoxDone = 0x80000000u;   // mailbox: the wave has ended and left nothing / its paths were adopted
-constexpr uint32_t kDonate = 16u;            // paths a wave parks at most (30 words each in its CAP * 64-word candidate area)
-constexpr size_t kBvhCtlBytes = 64u;         // mailboxes + running-wave count, after the lists
 // NLDS: node records and links staged in LDS (else read from global memory / L2: any scene size).
 // 8-wave workgroups are held to 80 VGPRs (6 waves per SIMD, three workgroups per CU): the walk is a
 // chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
@@ -423,10 +417,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     // 256 times per workgroup instead of 12 times per sample
     float* lut = reinterpret_cast<float*>(lds_b);                          // the first KiB
     for (uint32_t i = threadIdx.x; i < 256u; i += 64 * WAVES) lut[i] = (float)i / 255.0f;
-    // End-of-frame lane migration (see the outer loop): one mailbox word per wave + the count of waves still running
-    constexpr bool MIGRATE = RT_BVH_MIGRATE && NLDS && WAVES == 8 && CAP * 64 >= 30 * (int)kDonate;
-    uint32_t* const box = lists + WAVES * CAP * 64 + WAVES * 128;          // after the `best` slots
-    if (MIGRATE && threadIdx.x <= WAVES) box[threadIdx.x] = threadIdx.x == WAVES ? (uint32_t)WAVES : 0u;
     __syncthreads();
 
     const Scene sc = unpack_scene(A);
@@ -440,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     constexpr uint32_t kGrab = RT_BVH_GRAB;
     const uint32_t plenty = gridDim.x * (uint32_t)WAVES * 64u * 16u;  // sixteen tiles per resident wave
     uint32_t grab = 64u, trips = 0u;                                  // wave-uniform
-    bool exhausted = false, last_alive = false;
+    bool exhausted = false;
 #ifdef RT_BVH_COUNT
     const uint64_t clk0 = wall_clock64();      // 100 MHz
     uint64_t clk_x = 0;                        // when this wave found the cursor exhausted
@@ -493,7 +483,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 chunk_first = cur;
                 chunk_ty = (cur >> 6) / tiles_x;
                 chunk_tx = (cur >> 6) - chunk_ty * tiles_x;
-                chunk_ty = (chunk_ty * A.bvh_row_mul) % A.n_local_tiles;     // launch_bvh_as: rows of all costs at all times
             }
             const uint32_t tile_end = min(end, (cur & ~63u) + 64u);
             const uint32_t take = min((uint32_t)__popcll(idle), tile_end - cur);
@@ -517,89 +506,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
             }
             cur += take;
             idle = __ballot(!active);
-        }
-        if (MIGRATE && exhausted) {
-            // ---- the frame's pixels are handed out: thin waves merge ----
-            // From here on every wave only loses lanes, and a wave costs the SIMD the same issue slots with 5
-            // lanes as with 64: the end of a frame is thousands of nearly empty waves slowing each other down.
-            // A wave that is down to kDonate paths parks them in its own (empty) candidate area, posts their
-            // number in its mailbox and ends; a wave with that many free lanes adopts them.  `alive` (box[WAVES])
-            // counts the waves that have neither ended nor parked: the last one never parks and only ends once
-            // every other mailbox reads kBoxDone, so no path is lost.  Pixels do not care which lane finishes them.
-            bool parked = false, quit = false;
-            for (;;) {
-                const uint64_t act = __ballot(active);
-                const uint32_t na = (uint32_t)__popcll(act);
-                const uint32_t bx = (lane < (uint32_t)WAVES && lane != wave)
-                    ? __hip_atomic_load(&box[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : kBoxDone;
-                const uint64_t fits = __ballot(bx - 1u < 64u - na);        // 1 <= bx <= free lanes (0 and kBoxDone wrap out)
-                if (fits != 0ull) {
-                    const uint32_t src = (uint32_t)__builtin_ctzll(fits);
-                    const uint32_t k = (uint32_t)__shfl((int)bx, (int)src, 64);
-                    uint32_t won = 0u;
-                    if (lane == 0u) {
-                        uint32_t expect = k;
-                        won = __hip_atomic_compare_exchange_strong(&box[src], &expect, kBoxDone, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
-                    }
-                    won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
-#ifdef RT_BVH_COUNT
-                    if (RT_BVH_COUNT == 11) nrays += (won && lane == 0u) ? 1u : 0u;    // adoptions (wave)
-                    if (RT_BVH_COUNT == 12) nrays += (won && lane == 0u) ? k : 0u;     // adopted paths
-#endif
-                    if (won) {
-                        const uint32_t r = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
-                        if (!active && r < k) {
-                            const uint32_t* in = lists + src * (uint32_t)(CAP * 64) + r;
-                            auto F = [&](int f) { return __uint_as_float(in[f * (int)kDonate]); };
-                            const uint32_t w0 = in[0];
-                            shadow = (w0 >> 31) != 0u; bounce = w0 & 0x7FFFFFFFu;
-                            opix = in[1 * kDonate]; node = in[2 * kDonate]; idx = (int)in[3 * kDonate];
-                            t = F(4); dist = F(5); affect = F(6); sum = F(7); distance = F(8);
-                            ro = V(F(9), F(10), F(11)); rd = V(F(12), F(13), F(14)); color = V(F(15), F(16), F(17));
-                            fog = V(F(18), F(19), F(20)); normal = V(F(21), F(22), F(23)); sdir = V(F(24), F(25), F(26));
-                            albedo = V(F(27), F(28), F(29));
-                            active = true;
-                        }
-                    }
-                    continue;                                               // more may fit
-                }
-                if (na > kDonate || (na != 0u && last_alive)) break;        // work on
-                if (!last_alive) {                                          // may this wave go?
-                    uint32_t old = 2u;
-                    if (lane == 0u) old = __hip_atomic_fetch_add(&box[WAVES], 0xFFFFFFFFu, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-                    if (old <= 1u) {                                        // no: it is the last one running
-                        if (lane == 0u) __hip_atomic_fetch_add(&box[WAVES], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        last_alive = true;
-                        continue;
-                    }
-                    if (na != 0u) {
-                        const uint32_t r = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
-                        if (active) {
-                            uint32_t* out = lists + wave * (uint32_t)(CAP * 64) + r;
-                            auto S = [&](int f, float v) { out[f * (int)kDonate] = __float_as_uint(v); };
-                            out[0] = (shadow ? 0x80000000u : 0u) | bounce;
-                            out[1 * kDonate] = opix; out[2 * kDonate] = node; out[3 * kDonate] = (uint32_t)idx;
-                            S(4, t); S(5, dist); S(6, affect); S(7, sum); S(8, distance);
-                            S(9, ro.x); S(10, ro.y); S(11, ro.z); S(12, rd.x); S(13, rd.y); S(14, rd.z);
-                            S(15, color.x); S(16, color.y); S(17, color.z); S(18, fog.x); S(19, fog.y); S(20, fog.z);
-                            S(21, normal.x); S(22, normal.y); S(23, normal.z); S(24, sdir.x); S(25, sdir.y); S(26, sdir.z);
-                            S(27, albedo.x); S(28, albedo.y); S(29, albedo.z);
-                        }
-                        parked = true;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0u) __hip_atomic_store(&box[wave], na != 0u ? na : kBoxDone, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    quit = true;
-                    break;
-                }
-                // last wave running, nothing in hand: wait for the others' mailboxes
-                if (__ballot(bx != kBoxDone) == 0ull) { quit = true; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            (void)parked;
-            if (quit) break;
         }
         if (__ballot(active) == 0ull) break;
 
@@ -675,16 +581,8 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     RtFrameArgs a = a0;
     a.bvh_tail = (uint32_t)TAIL;
     if (TAIL == RT_BVH_TAIL_SMALL && a.grid_share <= 1u) a.bvh_tail = RT_BVH_TAIL_SERIAL;
-    a.bvh_row_mul = 1u;
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_TAIL")) a.bvh_tail = (uint32_t)atoi(e);
-    if (const char* e = getenv("RT355_BVH_ROWMUL")) {
-        uint32_t k = (uint32_t)atoi(e);
-        auto gcd = [](uint32_t x, uint32_t y) { while (y) { uint32_t t = x % y; x = y; y = t; } return x; };
-        while (k > 1u && gcd(k, a.n_local_tiles) != 1u) ++k;
-        a.bvh_row_mul = k ? k % a.n_local_tiles : 1u;
-        if (a.bvh_row_mul == 0u) a.bvh_row_mul = 1u;
-    }
 #endif
     auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, true> : bvh_pixels<WAVES, SGN, NLDS, CAP, false>;
     if (lds > 48u * 1024u) {
@@ -725,7 +623,7 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     // per wave: CAP x 64 candidate entries + 64 eight-byte slots of running nearest hits.  Scenes whose nodes
     // leave room for one 16-wave workgroup only (C5: 128 KB of nodes) get six-entry lists: 2 KB per wave again.
     constexpr size_t per_wave = (size_t)CAP * 256u + 512u, per_wave6 = 6u * 256u + 512u;
-    if (nodes + 8u * per_wave + kBvhCtlBytes <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * per_wave + kBvhCtlBytes, s);
+    if (nodes + 8u * per_wave <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * per_wave, s);
     if (nodes + 16u * per_wave <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave, s);
     if (nodes + 16u * per_wave6 <= cap)    return launch_bvh_as<16, SGN, true, 6, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave6, s);
     return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * per_wave, s);

@@ -59,7 +59,6 @@ struct RtFrameArgs {
     const uint32_t* bvh_link;  // [bvh_nodes] inner node: 4 * (index after its subtree); leaf: 0x80000000 | sphere
     uint32_t bvh_nodes;        // 0: no hierarchy built
     uint32_t grid_share;       // >1: this frame's persistent grid takes 1/grid_share of the chip (frames in flight)
-    uint32_t bvh_row_mul;      // tile row visited k-th by the pixel cursor = (k * bvh_row_mul) mod n_local_tiles (coprime; 1: in order)
     uint32_t bvh_tail;         // lanes still walking below which a wave leaves the walk for the shading pass (0: never)
 };
 
