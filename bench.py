@@ -45,6 +45,8 @@ if ROOT not in sys.path:
 # HIP's default of 4 hardware queues several of them share one queue and serialise (measured: 3.67
 # instead of 2.43 ms per frame through the N > 1 path).  Must be set before the HIP runtime loads.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver: dmabuf IPC only (RCCL peer access between ranks)
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")          # one node: RCCL's bootstrap needs no other interface
 
 FLOP_PER_TEST = 25          # WGSL-literal count of HK:308-311
 PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)" = 1024 SIMDs x 64 flop/clk x 2.4 GHz

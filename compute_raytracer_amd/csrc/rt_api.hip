@@ -190,6 +190,7 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_scene);
     for (int i = 0; i < 6; ++i) (void)hipFree(c->d_face[i]);
     for (int k = 0; k < kStreams; ++k) (void)hipFree(c->d_outs[k]);
+    for (int k = 0; k < kStreams; ++k) (void)hipFree(c->d_fin[k]);
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
@@ -262,6 +263,20 @@ static int ensure_queue(rt_ctx* c) {
         c->queue_cap = 0;
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_queue), entries * 3u * sizeof(float4)));
         c->queue_cap = entries;
+    }
+    return RT_OK;
+}
+
+// End-of-path records for the hierarchy kernel under a textured sky (32 B per local pixel slot, one buffer per
+// frame that may be in flight on its own stream): allocated when a frame first needs them.
+static int ensure_fin(rt_ctx* c) {
+    const size_t slots = (size_t)rt_padded_tiles(c->H, c->world) * 8u * c->W;
+    if (slots > c->fin_slots) {
+        { int rc = drain(c); if (rc != RT_OK) return rc; }
+        for (int k = 0; k < kStreams; ++k) { (void)hipFree(c->d_fin[k]); c->d_fin[k] = nullptr; }
+        c->fin_slots = 0;
+        for (int k = 0; k < kStreams; ++k) RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_fin[k]), slots * 2u * sizeof(float4)));
+        c->fin_slots = slots;
     }
     return RT_OK;
 }
@@ -490,6 +505,11 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     const bool need_bvh = use_bvh && !c->bvh_valid;
 
     if (queue_pipeline) { int rc = ensure_queue(c); if (rc != RT_OK) return rc; }
+    bool sky_flat = true;       // six 1x1 faces of one colour
+    for (int i = 0; i < 6; ++i)
+        if (c->fw[i] != 1u || c->fh[i] != 1u || c->face_texel0[i] != c->face_texel0[0]) sky_flat = false;
+    const bool resolve_pass = use_bvh && !sky_flat;      // rt_bvh.hip: sky_resolve
+    if (resolve_pass) { int rc = ensure_fin(c); if (rc != RT_OK) return rc; }
     // The hierarchy after rt_write_spheres.  A changed sphere count (or the first frame): host build, here and
     // now.  The same count: the topology on the device stays, its node bounds are refitted there (below);
     // a topology the worker thread has finished meanwhile is taken first.  Either way the device arrays may be
@@ -608,13 +628,14 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     unsigned long long* counters = c->d_rays + (kCtrlBytes / 8u) * slot;
     unsigned long long* ctrl = counters + kCounterBytes / 8u;
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
-    fa.sky_flat = 1u;       // six 1x1 faces of one colour
+    fa.sky_flat = sky_flat ? 1u : 0u;
     fa.sky_seamless = 1u;   // six equal squares: what WebGPU accepts as a cube texture (CM:35-79: 512 x 512 x 6)
-    for (int i = 0; i < 6; ++i) {
-        if (c->fw[i] != 1u || c->fh[i] != 1u || c->face_texel0[i] != c->face_texel0[0]) fa.sky_flat = 0u;
+    for (int i = 0; i < 6; ++i)
         if (c->fw[i] != c->fw[0] || c->fh[i] != c->fw[0]) fa.sky_seamless = 0u;
-    }
     fa.out = dst;
+    // one record buffer per frame that may be running: the frame kStreams slots back must be through with this one
+    fa.fin = resolve_pass ? c->d_fin[slot % (uint32_t)kStreams] : nullptr;
+    if (resolve_pass && slot >= (uint32_t)kStreams) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[slot - (uint32_t)kStreams], 0));
     fa.rays = counters;
     fa.queue = queue_pipeline ? c->d_queue : nullptr;   // rt_kernels.hip takes the pipeline only with a queue
     fa.qctrl = reinterpret_cast<uint32_t*>(ctrl) + 2;

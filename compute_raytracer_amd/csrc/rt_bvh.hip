@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
                     opix = (ty * 8u + row) * A.W + x;
                     ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
-                    if (sc.bounces == 0u) fog = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 2>(A, rd, lut));   // no ray will be cast
+                    if (FLAT && sc.bounces == 0u) fog = scale(sc.minIntensity, cube_sample<1>(A, rd, lut));   // no ray will be cast
                     color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
                     affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
                     shadow = false;
@@ -510,6 +510,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
         if (__ballot(active) == 0ull) break;
 
         bool finished = active && sc.bounces == 0u;
+        bool missed = false;
         const bool walking = node != n;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
@@ -525,11 +526,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 if (bounce == 0u) dist = idx >= 0 ? t : 0.0f;            // RK:116-118
                 // One sky sample serves RK:124 (the ray missed) and RK:93-96 (the fog colour of
                 // the pixel = the sky along the PRIMARY direction, which is rd at bounce 0).
+                // A textured sky (!FLAT) is not sampled here at all: the lane leaves a record, sky_resolve does it.
                 v3 sky = V(0, 0, 0);
-                if (bounce == 0u || idx < 0) sky = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 2>(A, rd, lut));
-                if (bounce == 0u) fog = sky;
+                if (FLAT && (bounce == 0u || idx < 0)) sky = scale(sc.minIntensity, cube_sample<1>(A, rd, lut));
+                if (FLAT && bounce == 0u) fog = sky;
                 if (idx < 0) {                                           // RK:122-126
-                    color = divs(add(scale(sum, color), scale(affect, sky)), next);
+                    if (FLAT) color = divs(add(scale(sum, color), scale(affect, sky)), next);
+                    else missed = true;
                     finished = true;
                 } else {
                     const float4 g = A.geo[idx];
@@ -557,7 +560,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
             }
         }
         if (finished) {
-            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel_sky(fog, color, dist);   // RK:91-98
+            if (FLAT) {
+                reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel_sky(fog, color, dist);   // RK:91-98
+            } else {
+                // dist is +0 or a hit distance > 0.001: its sign bit is free for the flag
+                A.fin[2u * opix] = make_float4(color.x, color.y, color.z, __uint_as_float(__float_as_uint(dist) | (missed ? 0x80000000u : 0u)));
+                if (missed && bounce != 0u) A.fin[2u * opix + 1u] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(bounce));
+            }
             active = false;
         }
     }
@@ -570,6 +579,43 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     }
 #endif
     count_rays(A.rays, nrays);
+}
+
+// Textured sky: the second half of every pixel of bvh_pixels<..., FLAT = false>.  In the state machine the
+// seamless cube filter (four taps, edge folds, corner rule) ran once per trip of a wave's outer loop for
+// however few lanes needed it, and cost the kernel 47 spilled VGPRs (C3 with a 6 x 512^2 sky: 2.78 ms against
+// 1.91 with a flat one).  Here it runs pixel per lane, full waves, neighbouring directions: the same
+// statements on the same values -- RK:93-96 (fog colour = sky along the primary ray), RK:122-126 (the miss
+// blended into the running mean; affect and sum are rebuilt by the RK:139-140 recurrence from the bounce
+// count), RK:91-98 (compose, pack) --, 68 bytes of HBM traffic per pixel.
+__global__ __launch_bounds__(256) void sky_resolve(const RtFrameArgs A) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    __syncthreads();
+    const Scene sc = unpack_scene(A);
+    const uint32_t slots = A.n_local_tiles * 8u * A.W;
+    for (uint32_t opix = blockIdx.x * 256u + threadIdx.x; opix < slots; opix += gridDim.x * 256u) {
+        const uint32_t lrow = opix / A.W, x = opix - lrow * A.W;
+        const uint32_t y = (A.tile_first + (lrow >> 3) * A.tile_step) * 8u + (lrow & 7u);
+        if (y >= A.H) continue;                                    // padding rows of the last tile: no pixel (RR:445)
+        const float4 r0 = A.fin[2u * opix];
+        const v3 fog = scale(sc.minIntensity, cube_sample<2>(A, primary_dir(A, sc, x, y), lut));
+        v3 color = V(r0.x, r0.y, r0.z);
+        const float dist = __uint_as_float(__float_as_uint(r0.w) & 0x7FFFFFFFu);
+        if ((__float_as_uint(r0.w) >> 31) != 0u) {
+            // a miss at bounce 0 left dist = +0 (RK:116-118) and no second record; later misses follow a hit at t > 0.001
+            float4 r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (dist != 0.0f) r1 = A.fin[2u * opix + 1u];
+            const uint32_t k = min(__float_as_uint(r1.w), sc.bounces);   // a path has bounced fewer than maxBounces times when it misses
+            float affect = 1.0f, sum = 0.0f;                        // RK:106-107
+            for (uint32_t i = 0; i < k; ++i) { const float next = affect + sum; affect = affect / 2.0f; sum = next; }   // RK:120, 139-140
+            const float next = affect + sum;
+            // at bounce 0 the missing ray IS the primary ray: one sample serves both, as in the reference's flow
+            const v3 sky = k == 0u ? fog : scale(sc.minIntensity, cube_sample<2>(A, V(r1.x, r1.y, r1.z), lut));
+            color = divs(add(scale(sum, color), scale(affect, sky)), next);      // RK:124
+        }
+        reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel_sky(fog, color, dist);
+    }
 }
 
 template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
@@ -608,7 +654,12 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_BLOCKS")) if (atoi(e) > 0) blocks = std::min((uint32_t)atoi(e), need);
 #endif
+    if (!a.sky_flat && !a.fin) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
+    if (!a.sky_flat) {
+        const uint32_t slots = a.n_local_tiles * 8u * a.W;
+        hipLaunchKernelGGL(sky_resolve, dim3(std::min((slots + 255u) / 256u, 256u * 8u)), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 

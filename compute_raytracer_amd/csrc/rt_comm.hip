@@ -31,6 +31,7 @@ struct rt_comm_state {
     int latest = -1;                       // buffer set of the latest rt_render_gather (-1: none yet)
     bool latest_has_frame = false;         // this rank received that frame
     hipEvent_t ev_r1[RT355_MAX_IN_FLIGHT] = {nullptr};   // end of the render, before the exchange
+    hipEvent_t ev_x1[RT355_MAX_IN_FLIGHT] = {nullptr};   // end of the exchange, before the de-interleave
     bool slot_gathered[RT355_MAX_IN_FLIGHT] = {false};
 };
 
@@ -64,6 +65,8 @@ void rt_comm_release(rt_ctx* c) {
     free_buffers(s);
     for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i)
         if (s->ev_r1[i]) (void)hipEventDestroy(s->ev_r1[i]);
+    for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i)
+        if (s->ev_x1[i]) (void)hipEventDestroy(s->ev_x1[i]);
     if (s->comm && s->owns_comm) (void)ncclCommDestroy(s->comm);
     delete s;
     c->comm = nullptr;
@@ -102,6 +105,7 @@ static int attach(rt_ctx* c, ncclComm_t comm, bool owns, uint32_t rank, uint32_t
     s->owns_comm = owns;
     for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) {
         hipError_t e = hipEventCreate(&s->ev_r1[i]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_x1[i], hipEventDisableTiming);
         if (e != hipSuccess) {
             c->comm = s;
             rt_comm_release(c);
@@ -151,6 +155,16 @@ static int render_part(rt_ctx* c, int root, uint32_t k, uint8_t** part) {
     return RT_OK;
 }
 
+// Frames in flight sit on different streams, and every rank must run the exchanges of one communicator in
+// the same order: the order of the calls.  That order is made explicit on the device -- the exchange of a
+// frame waits for the exchange of the frame enqueued before it (not for its de-interleave, and the renders
+// stay free to overlap) -- instead of being left to how RCCL treats one communicator on several streams.
+static int order_exchange(rt_ctx* c, uint32_t k) {
+    const uint32_t slot = c->in_flight - 1u;
+    if (slot > 0u) RT_HIP(hipStreamWaitEvent(c->streams[k], c->comm->ev_x1[slot - 1u], 0));
+    return RT_OK;
+}
+
 static int exchange_part(rt_ctx* c, int root, uint32_t k, uint8_t* part) {
     rt_comm_state* s = c->comm;
     const size_t msg = message_bytes(c);
@@ -170,6 +184,7 @@ static int finish_part(rt_ctx* c, int root, uint32_t k, uint8_t* part) {
     rt_comm_state* s = c->comm;
     const bool receives = root < 0 || (uint32_t)root == c->rank;
     hipStream_t st = c->streams[k];
+    RT_HIP(hipEventRecord(s->ev_x1[c->in_flight - 1u], st));
     if (receives)
         RT_HIP(rt_launch_assemble(s->d_gather[k], s->d_frame[k], c->W, c->H, c->world, rt_padded_tiles(c->H, c->world), st));
     // the frame is complete when the exchange and the de-interleave are: move the slot's end event
@@ -239,6 +254,7 @@ int rt_render_gather(rt_ctx* c, int root) {
     const uint32_t k = c->frames_rendered % (uint32_t)kStreams;
     uint8_t* part = nullptr;
     { int rc = render_part(c, root, k, &part); if (rc != RT_OK) return rc; }
+    { int rc = order_exchange(c, k); if (rc != RT_OK) return rc; }
     RT_NCCL(ncclGroupStart());
     int rc = exchange_part(c, root, k, part);
     ncclResult_t ge = ncclGroupEnd();
@@ -329,6 +345,7 @@ int rt_group_render(rt_group* g, int root) {
         RT_HIP(hipSetDevice(c->device));
         k[d] = c->frames_rendered % (uint32_t)kStreams;
         { int rc = render_part(c, root, k[d], &part[d]); if (rc != RT_OK) return rc; }
+        { int rc = order_exchange(c, k[d]); if (rc != RT_OK) return rc; }
     }
     RT_NCCL(ncclGroupStart());
     int rc = RT_OK;

@@ -79,6 +79,8 @@ struct rt_ctx {
     uint32_t face_texel0[6] = {0, 0, 0, 0, 0, 0};   // first texel (rgb) of each face: a one-texel sky of one colour is "flat"
     uint8_t* d_out = nullptr;              // colour buffer of the LATEST rt_render (one of d_outs)
     uint8_t* d_outs[kStreams] = {nullptr};
+    float4* d_fin[kStreams] = {nullptr};         // end-of-path records of frames with a textured sky (rt_bvh.hip: sky_resolve), lazily
+    size_t fin_slots = 0;                        // pixel slots each of them holds
     size_t out_bytes = 0;
     // per frame in flight: RT_RAY_COUNTERS partial ray counters (kCtrlBytes - 32 bytes), then a 32-byte
     // control block: unused u64, queue count, queue head, pixel / tile-pair cursor

@@ -151,6 +151,17 @@ __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = 
         return V(c.x + z, c.y + z, c.z + z);
     }
     if (SKY == 1) return V(0, 0, 0);   // not reached
+    if (A.sky_seamless && x0 >= 0 && x0 + 1 < w && y0 >= 0 && y0 + 1 < w) {
+        // all four taps on the selected face (all but one sample in a few hundred): the tap pairs of a row are
+        // adjacent texels, one 8-byte load each; same lerps as below
+        const uint2 r0 = *reinterpret_cast<const uint2*>(f + 4u * ((size_t)y0 * (size_t)w + (size_t)x0));
+        const uint2 r1 = *reinterpret_cast<const uint2*>(f + 4u * ((size_t)(y0 + 1) * (size_t)w + (size_t)x0));
+        auto un = [&](uint32_t p) {
+            if (lut) return V(lut[p & 255u], lut[(p >> 8) & 255u], lut[(p >> 16) & 255u]);
+            return V((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f);
+        };
+        return lerp3(lerp3(un(r0.x), un(r0.y), wu), lerp3(un(r1.x), un(r1.y), wu), wv);
+    }
     if (A.sky_seamless && x0 >= -1 && x0 < w && y0 >= -1 && y0 < w) {
         v3 top = V(0, 0, 0), row = V(0, 0, 0);
 #pragma unroll 1

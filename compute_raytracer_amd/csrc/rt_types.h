@@ -47,6 +47,11 @@ struct RtFrameArgs {
     uint32_t sky_flat;         // every face is ONE texel and the six texels agree (the constant sky of C1-C4)
     uint32_t sky_seamless;     // six equal square faces = a WebGPU cube texture: seamless filtering across edges
     uint8_t* out;              // compact tile buffer [n_local_tiles*8][W][4]
+    // Textured sky, hierarchy path: bvh_pixels leaves every pixel's end-of-path record here and sky_resolve
+    // samples the cube map and composes the pixel (rt_bvh.hip).  2 float4 per pixel slot of `out`:
+    // {colour rgb, dist | sign bit = the path ended on a miss}, and for a miss after bounce 0
+    // {direction of the missing ray, bounce count as bits}
+    float4* fin;
     unsigned long long* rays;  // scene-traversal counter: RT_RAY_COUNTERS partial sums (one atomicAdd per wave)
     // path queue between the first-bounce kernel and the path kernel (two-kernel pipeline):
     // 3 float4 per surviving path {ro.xyz, pixel index}, {rd.xyz, dist}, {color.rgb, 0}

@@ -10,7 +10,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "7,4").split(",")]
 cfg = rt.BASELINE_CONFIGS[name]
 scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
-sky = rt.CubemapMaterial.synthetic_daylight() if cfg["skybox"] else None
+sky = rt.CubemapMaterial.synthetic_daylight() if (cfg["skybox"] or os.environ.get("RT355_PROBE_SKY")) else None
 fr = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "frames.json"))).get(name)
 for world in (1, 8):
     for v in variants:
