@@ -21,6 +21,9 @@
 #include "rt_device.h"
 #include "rt_tri_types.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace rtk {
 
 constexpr uint32_t kStack = 20u;                                  // RK:71
@@ -115,9 +118,11 @@ __device__ __forceinline__ bool hit_triangle(const RtTriScene& T, uint32_t ti, v
 }
 
 // RK:246-332 traceBLAS (the normal transform RK:334-338 is deferred to finish_hit)
-template <bool COUNT>
+// STK: the element type of the traversal stacks.  uint16_t when the node buffer has at most 65,536 entries:
+// an index is stored clamped to the last node, which is what load_node makes of it anyway.
+template <bool COUNT, typename STK>
 __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L, uint32_t bi, v3 o, v3 d, float& nearest,
-                                           TriHit& hit, uint32_t* stack, uint32_t stride, float& traces) {
+                                           TriHit& hit, STK* stack, uint32_t stride, float& traces) {
     float m[17];                                                    // mat4 column-major, m[4c + r]; m[16] root index
     if (bi < L.n_blas) {
 #pragma unroll
@@ -156,7 +161,7 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
                 node = swap ? c2 : c1;                              // RK:302 tree[iChild1]
                 (void)i1;
                 if (d2 < blasNearest) {                             // RK:303
-                    stack[sclamp(sp) * stride] = i2;                // RK:304 (no overflow guard upstream)
+                    stack[sclamp(sp) * stride] = (STK)(i2 < T.n_nodes ? i2 : T.n_nodes - 1u);   // RK:304 (no overflow guard upstream)
                     sp += 1u;
                 }
             }
@@ -182,9 +187,9 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
 }
 
 // RK:168-244 traceTLAS.  tstack / bstack: this lane's two LDS stacks.
-template <bool COUNT>
-__device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& L, v3 o, v3 d, uint32_t* tstack,
-                                             uint32_t* bstack, uint32_t stride, float& traces) {
+template <bool COUNT, typename STK>
+__device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& L, v3 o, v3 d, STK* tstack,
+                                             STK* bstack, uint32_t stride, float& traces) {
     TriHit hit; hit.t = 0.0f; hit.u = hit.v = 0.0f; hit.tri = -1; hit.blas = -1;   // RK:170-171
     float nearest = 9999.0f;                                        // RK:172
     const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -208,7 +213,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
             } else {
                 node = swap ? c2 : c1;                              // RK:208
                 if (d2 < nearest) {                                 // RK:209
-                    tstack[sclamp(sp) * stride] = i2;
+                    tstack[sclamp(sp) * stride] = (STK)(i2 < T.n_nodes ? i2 : T.n_nodes - 1u);
                     sp += 1u;
                     // RK:212-214 guards with `>`, the heatmap twin with `>=` (HK:168)
                     if (COUNT ? sp >= kStack : sp > kStack) sp = kStack - 1u;
@@ -220,7 +225,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
                 if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
                 uint32_t bi = u32f(T.blas_lookup[li]);              // RK:223
                 if (bi >= T.n_blas) bi = T.n_blas - 1u;
-                trace_blas<COUNT>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
+                trace_blas<COUNT, STK>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
             }
             if (sp == 0u) break;                                    // RK:233
             sp -= 1u;
@@ -230,22 +235,28 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
     return hit;
 }
 
-// What hitTriangle (RK:381-387) and traceBLAS (RK:334-338) attach to the accepted hit.
-struct Surface { v3 normal; float u, v; v3 rgb; float w; };
-__device__ __forceinline__ Surface finish_hit(const RtTriScene& T, const TriHit& h) {
+// What hitTriangle (RK:381-387) and traceBLAS (RK:334-338) attach to the accepted hit -- in two parts, so that
+// only the normal (which the reflection needs) is carried across the shadow ray's traversal; texture
+// coordinate and colour are read when the bounce is shaded.
+__device__ __forceinline__ v3 hit_normal(const RtTriScene& T, const TriHit& h) {
     const float* tr = T.tri + 40u * (size_t)h.tri;
     const float w = 1.0f - h.u - h.v;                                                // RK:381
     const v3 nA = V(tr[4], tr[5], tr[6]), nB = V(tr[16], tr[17], tr[18]), nC = V(tr[28], tr[29], tr[30]);
     const v3 n = add(add(scale(w, nA), scale(h.u, nB)), scale(h.v, nC));             // RK:382
-    Surface s;
-    s.u = (tr[8] * w + tr[20] * h.u) + tr[32] * h.v;                                 // RK:386
-    s.v = 1.0f - ((tr[9] * w + tr[21] * h.u) + tr[33] * h.v);                        // RK:386-387
-    s.rgb = V(tr[36], tr[37], tr[38]); s.w = tr[39];                                 // RK:384
     const float* m = T.blas + 20u * (size_t)h.blas;
     const v3 tn = V(((m[0] * n.x + m[1] * n.y) + m[2] * n.z) + m[3] * 0.0f,
                     ((m[4] * n.x + m[5] * n.y) + m[6] * n.z) + m[7] * 0.0f,
                     ((m[8] * n.x + m[9] * n.y) + m[10] * n.z) + m[11] * 0.0f);       // RK:335-337
-    s.normal = normalize(tn);
+    return normalize(tn);
+}
+struct Albedo { float u, v; v3 rgb; float w; };
+__device__ __forceinline__ Albedo hit_albedo(const RtTriScene& T, int tri, float hu, float hv) {
+    const float* tr = T.tri + 40u * (size_t)tri;
+    const float w = 1.0f - hu - hv;                                                  // RK:381
+    Albedo s;
+    s.u = (tr[8] * w + tr[20] * hu) + tr[32] * hv;                                   // RK:386
+    s.v = 1.0f - ((tr[9] * w + tr[21] * hu) + tr[33] * hv);                          // RK:386-387
+    s.rgb = V(tr[36], tr[37], tr[38]); s.w = tr[39];                                 // RK:384
     return s;
 }
 
@@ -268,11 +279,11 @@ __device__ inline v3 tex2d_sample(const RtTriScene& T, float u, float v) {
 }
 
 // ---- kernel: RK main over the triangle scene ---------------------------------------------------------
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
-    __shared__ uint32_t stacks[2 * kStack * 64 * WAVES];
-    uint32_t* tstack = stacks + threadIdx.x;
-    uint32_t* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
+template <int WAVES, typename STK, int OCC>
+__global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
+    __shared__ STK stacks[2 * kStack * 64 * WAVES];
+    STK* tstack = stacks + threadIdx.x;
+    STK* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
     constexpr uint32_t stride = 64 * WAVES;
     __shared__ float4 s_nodes[2 * kLdsNodes];
     __shared__ float s_blas[20 * kLdsBlas];
@@ -285,15 +296,14 @@ __global__ __launch_bounds__(64 * WAVES) void trace_triangles(const RtFrameArgs 
     if (x >= A.W || y >= A.H) return;
 
     const Scene sc = unpack_scene(A);
-    const v3 dir0 = primary_dir(A, sc, x, y);
     uint32_t nrays = 0;
     float dummy = 0.0f;
     float dist = 0.0f;
     v3 color = V(1.0f, 1.0f, 1.0f);
-    v3 ro = sc.cameraPos, rd = dir0;
+    v3 ro = sc.cameraPos, rd = primary_dir(A, sc, x, y);
     float affect = 1.0f, sum = 0.0f;
     for (uint32_t bounce = 0; bounce < sc.bounces; ++bounce) {                       // RK:113
-        const TriHit h = trace_tlas<false>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
+        const TriHit h = trace_tlas<false, STK>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
         ++nrays;
         const bool hit = h.tri >= 0;
         if (bounce == 0) dist = hit ? h.t : 0.0f;                                    // RK:116-118
@@ -303,15 +313,18 @@ __global__ __launch_bounds__(64 * WAVES) void trace_triangles(const RtFrameArgs 
             color = divs(add(scale(sum, color), scale(affect, sky)), next);
             break;
         }
-        const Surface s = finish_hit(T, h);
+        const v3 normal = hit_normal(T, h);
+        const int tri = h.tri;
+        const float hu = h.u, hv = h.v;
         ro = add(ro, scale(h.t, rd));                                                // RK:129
-        rd = normalize(reflect(rd, s.normal));                                       // RK:130
+        rd = normalize(reflect(rd, normal));                                         // RK:130
         // RK:146-166
         const v3 sdir = normalize(sub(ro, sc.lightPos));
         const float distance = length(sdir);
-        const TriHit sh = trace_tlas<false>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
+        const TriHit sh = trace_tlas<false, STK>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
         ++nrays;
-        const float intensity = light_term(sc, ro, s.normal, sdir, distance, sh.tri >= 0, sh.t);
+        const float intensity = light_term(sc, ro, normal, sdir, distance, sh.tri >= 0, sh.t);
+        const Albedo s = hit_albedo(T, tri, hu, hv);
         const v3 diffuseColor = scale(s.w, s.rgb);                                   // RK:133
         const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));        // RK:134
         const v3 blended = scale(intensity, add(diffuseColor, samplerColor));        // RK:135
@@ -320,16 +333,142 @@ __global__ __launch_bounds__(64 * WAVES) void trace_triangles(const RtFrameArgs 
         sum = next;                                                                  // RK:140
     }
     const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;
-    reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, dir0, color, dist);   // RK:91-98
+    // the fog colour is the sky along the primary ray (RK:93-96): its direction is formed again here rather than
+    // carried through both traversals
+    reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, primary_dir(A, sc, x, y), color, dist);   // RK:91-98
+    count_rays(A.rays, nrays);
+}
+
+// ---- kernel: the same frame from persistent waves ---------------------------------------------------------
+// Pixel per lane wastes most of a wave: a path is 1 ray (sky) to 2 x maxBounces rays long (the bench scene:
+// 2.3 on average, 8 at most), and a wave lasts as long as its longest path.  Here a lane carries ONE path as a
+// small state machine -- reflection ray -> shadow ray -> next bounce (RK:101-144 unrolled) -- and takes the next
+// pixel from the frame's atomic cursor (whole 8x8 tiles per atomic, as rt_bvh.hip: bvh_pixels) when its path
+// ends; every trip of the loop traverses one ray per lane, reflection and shadow rays side by side, through
+// the single inlined copy of traceTLAS (half the code and fewer live registers than two call sites).  The
+// arithmetic per ray and per pixel is unchanged, statement for statement.
+template <int WAVES, typename STK, int OCC>
+__global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles_persistent(const RtFrameArgs A, const RtTriScene T) {
+    __shared__ STK stacks[2 * kStack * 64 * WAVES];
+    STK* tstack = stacks + threadIdx.x;
+    STK* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
+    constexpr uint32_t stride = 64 * WAVES;
+    __shared__ float4 s_nodes[2 * kLdsNodes];
+    __shared__ float s_blas[20 * kLdsBlas];
+    const TriLds L = stage_head<WAVES>(T, s_nodes, s_blas);
+    const uint32_t lane = threadIdx.x & 63u;
+    const Scene sc = unpack_scene(A);
+    const uint32_t tiles_x = (A.W + 7u) / 8u;
+    const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
+    uint32_t cur = 0, end = 0;                                   // wave-uniform chunk cursor
+    uint32_t chunk_ty = 0, chunk_tx = 0, chunk_first = ~0u;
+    const uint32_t plenty = gridDim.x * (uint32_t)WAVES * 64u * 16u;
+    uint32_t grab = 64u, trips = 0u;
+    bool exhausted = false;
+
+    bool active = false, shadow = false;
+    uint32_t opix = 0, bounce = 0, nrays = 0;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(1, 1, 1), normal = V(0, 0, 1), sdir = V(0, 0, 1);
+    float dist = 0.0f, affect = 1.0f, sum = 0.0f, distance = 1.0f, hu = 0.0f, hv = 0.0f;
+    int tri = -1;
+    float dummy = 0.0f;
+
+    for (;;) {
+        ++trips;
+        uint64_t idle = __ballot(!active);
+        while (idle && !exhausted) {
+            if (cur == end) {
+                // cheap pixels (sky) double the reservation up to four tiles while plenty of the frame is left,
+                // expensive ones go back to single tiles (rt_bvh.hip: bvh_pixels)
+                if (trips <= 2u && total - min(end, total) > plenty) grab = min(grab * 2u, 256u);
+                else if (trips > 8u) grab = 64u;
+                trips = 0u;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&A.qctrl[2], grab);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= total) { exhausted = true; break; }
+                cur = base;
+                end = min(base + grab, total);
+            }
+            if ((cur & 63u) == 0u || cur == chunk_first) {
+                chunk_first = cur;
+                chunk_ty = (cur >> 6) / tiles_x;
+                chunk_tx = (cur >> 6) - chunk_ty * tiles_x;
+            }
+            const uint32_t tile_end = min(end, (cur & ~63u) + 64u);
+            const uint32_t take = min((uint32_t)__popcll(idle), tile_end - cur);
+            const uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && r < take) {
+                const uint32_t l = (cur + r) & 63u;
+                const uint32_t x = chunk_tx * 8u + (l & 7u), row = l >> 3;
+                const uint32_t y = (A.tile_first + chunk_ty * A.tile_step) * 8u + row;
+                if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
+                    opix = (chunk_ty * 8u + row) * A.W + x;
+                    ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
+                    color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
+                    affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
+                    shadow = false;
+                    active = true;
+                }
+            }
+            cur += take;
+            idle = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+
+        bool finished = active && sc.bounces == 0u;                                  // RK:113: the loop body never runs
+        const bool tracing = active && !finished;
+        TriHit h; h.t = 0.0f; h.u = h.v = 0.0f; h.tri = -1; h.blas = -1;
+        if (tracing) h = trace_tlas<false, STK>(T, L, shadow ? sc.lightPos : ro, shadow ? sdir : rd, tstack, bstack, stride, dummy);   // RK:114 / RK:153
+        if (tracing) {
+            ++nrays;
+            const float next = affect + sum;                                         // RK:120
+            if (!shadow) {
+                const bool hit = h.tri >= 0;
+                if (bounce == 0u) dist = hit ? h.t : 0.0f;                           // RK:116-118
+                if (!hit) {                                                          // RK:122-126
+                    const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
+                    color = divs(add(scale(sum, color), scale(affect, sky)), next);
+                    finished = true;
+                } else {
+                    normal = hit_normal(T, h);
+                    tri = h.tri; hu = h.u; hv = h.v;
+                    ro = add(ro, scale(h.t, rd));                                    // RK:129
+                    rd = normalize(reflect(rd, normal));                             // RK:130
+                    sdir = normalize(sub(ro, sc.lightPos));                          // RK:147
+                    distance = length(sdir);                                         // RK:148
+                    shadow = true;                                                   // RK:153 next
+                }
+            } else {
+                const float intensity = light_term(sc, ro, normal, sdir, distance, h.tri >= 0, h.t);
+                const Albedo s = hit_albedo(T, tri, hu, hv);
+                const v3 diffuseColor = scale(s.w, s.rgb);                           // RK:133
+                const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));   // RK:134
+                const v3 blended = scale(intensity, add(diffuseColor, samplerColor));   // RK:135
+                color = divs(add(scale(sum, color), scale(affect, blended)), next);  // RK:136
+                affect = affect / 2.0f;                                              // RK:139
+                sum = next;                                                          // RK:140
+                ++bounce;
+                shadow = false;
+                finished = bounce >= sc.bounces;                                     // RK:113
+            }
+        }
+        if (finished) {
+            const uint32_t lrow = opix / A.W, x = opix - lrow * A.W;
+            const uint32_t y = (A.tile_first + (lrow >> 3) * A.tile_step) * 8u + (lrow & 7u);
+            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, primary_dir(A, sc, x, y), color, dist);   // RK:91-98
+            active = false;
+        }
+    }
     count_rays(A.rays, nrays);
 }
 
 // ---- kernel: the heatmap twin (HK:63-83) ------------------------------------------------------------
-template <int WAVES>
+template <int WAVES, typename STK>
 __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArgs A, const RtTriScene T) {
-    __shared__ uint32_t stacks[2 * kStack * 64 * WAVES];
-    uint32_t* tstack = stacks + threadIdx.x;
-    uint32_t* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
+    __shared__ STK stacks[2 * kStack * 64 * WAVES];
+    STK* tstack = stacks + threadIdx.x;
+    STK* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
     constexpr uint32_t stride = 64 * WAVES;
     __shared__ float4 s_nodes[2 * kLdsNodes];
     __shared__ float s_blas[20 * kLdsBlas];
@@ -342,7 +481,7 @@ __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArg
     const Scene sc = unpack_scene(A);
     const v3 dir0 = primary_dir(A, sc, x, y);                                        // HK:66-76
     float traces = 0.0f;
-    (void)trace_tlas<true>(T, L, sc.cameraPos, dir0, tstack, bstack, stride, traces);   // HK:96-99, one bounce
+    (void)trace_tlas<true, STK>(T, L, sc.cameraPos, dir0, tstack, bstack, stride, traces);   // HK:96-99, one bounce
     const float g = clampf(traces / 300.0f, 0.0f, 1.0f);                             // HK:79
     const uint32_t q = unorm8(g * 1.0f);                                             // HK:81-82
     const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;
@@ -352,11 +491,38 @@ __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArg
 
 }  // namespace rtk
 
-hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
-    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+template <typename STK>
+static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, int grid_mapped, hipStream_t s) {
     constexpr int WAVES = 4;
     dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
-    if (heatmap) hipLaunchKernelGGL(rtk::heatmap_triangles<WAVES>, grid, dim3(64 * WAVES), 0, s, a, t);
-    else         hipLaunchKernelGGL(rtk::trace_triangles<WAVES>, grid, dim3(64 * WAVES), 0, s, a, t);
+    if (heatmap) { hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK>), grid, dim3(64 * WAVES), 0, s, a, t); return; }
+    if (grid_mapped) { hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, 4>), grid, dim3(64 * WAVES), 0, s, a, t); return; }
+    int occ = 4;
+    uint32_t per_cu = 4u;                         // workgroups per CU the launch bounds allow (4 waves each)
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_OCC")) occ = atoi(e);
+    per_cu = (uint32_t)occ;
+    if (const char* e = getenv("RT355_TRI_PERCU")) per_cu = (uint32_t)atoi(e);
+#endif
+    uint32_t blocks = 256u * per_cu;
+    if (a.grid_share > 1u) blocks = std::max(256u, blocks / a.grid_share);
+    const uint32_t pixels = a.n_local_tiles * ((a.W + 7u) / 8u) * 64u;
+    blocks = std::min(blocks, (pixels + 64u * WAVES - 1u) / (64u * WAVES));
+    switch (occ) {
+    case 3: hipLaunchKernelGGL((rtk::trace_triangles_persistent<WAVES, STK, 3>), dim3(blocks), dim3(64 * WAVES), 0, s, a, t); break;
+    case 5: hipLaunchKernelGGL((rtk::trace_triangles_persistent<WAVES, STK, 5>), dim3(blocks), dim3(64 * WAVES), 0, s, a, t); break;
+    case 6: hipLaunchKernelGGL((rtk::trace_triangles_persistent<WAVES, STK, 6>), dim3(blocks), dim3(64 * WAVES), 0, s, a, t); break;
+    default: hipLaunchKernelGGL((rtk::trace_triangles_persistent<WAVES, STK, 4>), dim3(blocks), dim3(64 * WAVES), 0, s, a, t); break;
+    }
+}
+
+hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, int grid_mapped, hipStream_t s) {
+    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    bool narrow = t.n_nodes <= 65536u;
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_STK32")) narrow = narrow && atoi(e) == 0;
+#endif
+    if (narrow) launch_tri<uint16_t>(a, t, heatmap, grid_mapped, s);
+    else        launch_tri<uint32_t>(a, t, heatmap, grid_mapped, s);
     return hipGetLastError();
 }
