@@ -319,7 +319,7 @@ def main():
         value = rays_frame * a.steps / elapsed / 1e6
         label, hierarchy, queue_pipeline = kernel_label(a.mode, a.variant, N)
         if tri:
-            label, hierarchy, queue_pipeline = "trace_triangles<4> (TLAS/BLAS traversal, pixel per lane)", False, False
+            label, hierarchy, queue_pipeline = "trace_triangles (TLAS/BLAS traversal, pixel per lane, one 8x8 tile per single-wave workgroup)", False, False
         # launches of consecutive frames overlap on the device (each on a share of the chip): the chip-level
         # rate is work per launch / frame period; one frame at a time: / the launch duration.  The two-kernel
         # brute-force pipeline shares a path queue: its frames are serialised by the library.

@@ -659,7 +659,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.n_tri_lookup = (uint32_t)(c->d_tri_lookup.used / 4u);
         ts.n_blas_lookup = (uint32_t)(c->d_blas_lookup.used / 4u);
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
-        RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, c->variant == 1, s));   // variant 1: pixel per lane, one launch-mapped tile per wave
+        RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
     } else {
         if (use_bvh) RT_HIP(rt_launch_bvh(fa, s));
         else RT_HIP(rt_launch_trace(fa, cfg, s));

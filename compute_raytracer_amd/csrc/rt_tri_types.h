@@ -12,4 +12,4 @@ struct RtTriScene {
     uint32_t n_nodes, n_blas, n_tri, n_tri_lookup, n_blas_lookup, tex_w, tex_h;
 };
 
-hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, int grid_mapped, hipStream_t s);
+hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);

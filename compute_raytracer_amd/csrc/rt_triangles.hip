@@ -21,8 +21,6 @@
 #include "rt_device.h"
 #include "rt_tri_types.h"
 
-#include <algorithm>
-#include <cstdlib>
 
 namespace rtk {
 
@@ -339,130 +337,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     count_rays(A.rays, nrays);
 }
 
-// ---- kernel: the same frame from persistent waves ---------------------------------------------------------
-// Pixel per lane wastes most of a wave: a path is 1 ray (sky) to 2 x maxBounces rays long (the bench scene:
-// 2.3 on average, 8 at most), and a wave lasts as long as its longest path.  Here a lane carries ONE path as a
-// small state machine -- reflection ray -> shadow ray -> next bounce (RK:101-144 unrolled) -- and takes the next
-// pixel from the frame's atomic cursor (whole 8x8 tiles per atomic, as rt_bvh.hip: bvh_pixels) when its path
-// ends; every trip of the loop traverses one ray per lane, reflection and shadow rays side by side, through
-// the single inlined copy of traceTLAS (half the code and fewer live registers than two call sites).  The
-// arithmetic per ray and per pixel is unchanged, statement for statement.
-template <int WAVES, typename STK, int OCC>
-__global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles_persistent(const RtFrameArgs A, const RtTriScene T) {
-    __shared__ STK stacks[2 * kStack * 64 * WAVES];
-    STK* tstack = stacks + threadIdx.x;
-    STK* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
-    constexpr uint32_t stride = 64 * WAVES;
-    __shared__ float4 s_nodes[2 * kLdsNodes];
-    __shared__ float s_blas[20 * kLdsBlas];
-    const TriLds L = stage_head<WAVES>(T, s_nodes, s_blas);
-    const uint32_t lane = threadIdx.x & 63u;
-    const Scene sc = unpack_scene(A);
-    const uint32_t tiles_x = (A.W + 7u) / 8u;
-    const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
-    uint32_t cur = 0, end = 0;                                   // wave-uniform chunk cursor
-    uint32_t chunk_ty = 0, chunk_tx = 0, chunk_first = ~0u;
-    const uint32_t plenty = gridDim.x * (uint32_t)WAVES * 64u * 16u;
-    uint32_t grab = 64u, trips = 0u;
-    bool exhausted = false;
-
-    bool active = false, shadow = false;
-    uint32_t opix = 0, bounce = 0, nrays = 0;
-    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(1, 1, 1), normal = V(0, 0, 1), sdir = V(0, 0, 1);
-    float dist = 0.0f, affect = 1.0f, sum = 0.0f, distance = 1.0f, hu = 0.0f, hv = 0.0f;
-    int tri = -1;
-    float dummy = 0.0f;
-
-    for (;;) {
-        ++trips;
-        uint64_t idle = __ballot(!active);
-        while (idle && !exhausted) {
-            if (cur == end) {
-                // cheap pixels (sky) double the reservation up to four tiles while plenty of the frame is left,
-                // expensive ones go back to single tiles (rt_bvh.hip: bvh_pixels)
-                if (trips <= 2u && total - min(end, total) > plenty) grab = min(grab * 2u, 256u);
-                else if (trips > 8u) grab = 64u;
-                trips = 0u;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&A.qctrl[2], grab);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= total) { exhausted = true; break; }
-                cur = base;
-                end = min(base + grab, total);
-            }
-            if ((cur & 63u) == 0u || cur == chunk_first) {
-                chunk_first = cur;
-                chunk_ty = (cur >> 6) / tiles_x;
-                chunk_tx = (cur >> 6) - chunk_ty * tiles_x;
-            }
-            const uint32_t tile_end = min(end, (cur & ~63u) + 64u);
-            const uint32_t take = min((uint32_t)__popcll(idle), tile_end - cur);
-            const uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!active && r < take) {
-                const uint32_t l = (cur + r) & 63u;
-                const uint32_t x = chunk_tx * 8u + (l & 7u), row = l >> 3;
-                const uint32_t y = (A.tile_first + chunk_ty * A.tile_step) * 8u + row;
-                if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
-                    opix = (chunk_ty * 8u + row) * A.W + x;
-                    ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
-                    color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
-                    affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
-                    shadow = false;
-                    active = true;
-                }
-            }
-            cur += take;
-            idle = __ballot(!active);
-        }
-        if (__ballot(active) == 0ull) break;
-
-        bool finished = active && sc.bounces == 0u;                                  // RK:113: the loop body never runs
-        const bool tracing = active && !finished;
-        TriHit h; h.t = 0.0f; h.u = h.v = 0.0f; h.tri = -1; h.blas = -1;
-        if (tracing) h = trace_tlas<false, STK>(T, L, shadow ? sc.lightPos : ro, shadow ? sdir : rd, tstack, bstack, stride, dummy);   // RK:114 / RK:153
-        if (tracing) {
-            ++nrays;
-            const float next = affect + sum;                                         // RK:120
-            if (!shadow) {
-                const bool hit = h.tri >= 0;
-                if (bounce == 0u) dist = hit ? h.t : 0.0f;                           // RK:116-118
-                if (!hit) {                                                          // RK:122-126
-                    const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
-                    color = divs(add(scale(sum, color), scale(affect, sky)), next);
-                    finished = true;
-                } else {
-                    normal = hit_normal(T, h);
-                    tri = h.tri; hu = h.u; hv = h.v;
-                    ro = add(ro, scale(h.t, rd));                                    // RK:129
-                    rd = normalize(reflect(rd, normal));                             // RK:130
-                    sdir = normalize(sub(ro, sc.lightPos));                          // RK:147
-                    distance = length(sdir);                                         // RK:148
-                    shadow = true;                                                   // RK:153 next
-                }
-            } else {
-                const float intensity = light_term(sc, ro, normal, sdir, distance, h.tri >= 0, h.t);
-                const Albedo s = hit_albedo(T, tri, hu, hv);
-                const v3 diffuseColor = scale(s.w, s.rgb);                           // RK:133
-                const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));   // RK:134
-                const v3 blended = scale(intensity, add(diffuseColor, samplerColor));   // RK:135
-                color = divs(add(scale(sum, color), scale(affect, blended)), next);  // RK:136
-                affect = affect / 2.0f;                                              // RK:139
-                sum = next;                                                          // RK:140
-                ++bounce;
-                shadow = false;
-                finished = bounce >= sc.bounces;                                     // RK:113
-            }
-        }
-        if (finished) {
-            const uint32_t lrow = opix / A.W, x = opix - lrow * A.W;
-            const uint32_t y = (A.tile_first + (lrow >> 3) * A.tile_step) * 8u + (lrow & 7u);
-            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, primary_dir(A, sc, x, y), color, dist);   // RK:91-98
-            active = false;
-        }
-    }
-    count_rays(A.rays, nrays);
-}
-
 // ---- kernel: the heatmap twin (HK:63-83) ------------------------------------------------------------
 template <int WAVES, typename STK>
 __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArgs A, const RtTriScene T) {
@@ -491,38 +365,22 @@ __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArg
 
 }  // namespace rtk
 
-template <typename STK>
-static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, int grid_mapped, hipStream_t s) {
-    constexpr int WAVES = 4;
+// OCC: waves per SIMD the register allocation is held to.  16-bit stacks leave LDS room for four workgroups per
+// CU, and 128 VGPRs (one spilled dword) for the fourth wave per SIMD pay: 4K 0.92 -> 0.79 ms per frame with
+// frames in flight; five waves (96 VGPRs, 42 spilled) lose again (profiles/r02/tri_occ2.log).
+// WAVES: one wave per workgroup -- a workgroup's LDS and wave slots come free as soon as its own tile is done
+// (1 / 2 / 4 / 8 waves: 0.545 / 0.571 / 0.603 / 0.624 ms for the 1344x846 frame one at a time, 0.769 / 0.765 /
+// 0.792 / 0.883 ms per 4K frame in flight; profiles/r02/tri_waves.log).
+template <typename STK, int OCC, int WAVES = 1>
+static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
     dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
-    if (heatmap) { hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK>), grid, dim3(64 * WAVES), 0, s, a, t); return; }
-    if (grid_mapped) { hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, 4>), grid, dim3(64 * WAVES), 0, s, a, t); return; }
-    int occ = 4;
-    uint32_t per_cu = 4u;                         // workgroups per CU the launch bounds allow (4 waves each)
-#ifdef RT_TRI_DEV_ENV
-    if (const char* e = getenv("RT355_TRI_OCC")) occ = atoi(e);
-    per_cu = (uint32_t)occ;
-    if (const char* e = getenv("RT355_TRI_PERCU")) per_cu = (uint32_t)atoi(e);
-#endif
-    uint32_t blocks = 256u * per_cu;
-    if (a.grid_share > 1u) blocks = std::max(256u, blocks / a.grid_share);
-    const uint32_t pixels = a.n_local_tiles * ((a.W + 7u) / 8u) * 64u;
-    blocks = std::min(blocks, (pixels + 64u * WAVES - 1u) / (64u * WAVES));
-    switch (occ) {
-    case 3: hipLaunchKernelGGL((rtk::trace_triangles_persistent<WAVES, STK, 3>), dim3(blocks), dim3(64 * WAVES), 0, s, a, t); break;
-    case 5: hipLaunchKernelGGL((rtk::trace_triangles_persistent<WAVES, STK, 5>), dim3(blocks), dim3(64 * WAVES), 0, s, a, t); break;
-    case 6: hipLaunchKernelGGL((rtk::trace_triangles_persistent<WAVES, STK, 6>), dim3(blocks), dim3(64 * WAVES), 0, s, a, t); break;
-    default: hipLaunchKernelGGL((rtk::trace_triangles_persistent<WAVES, STK, 4>), dim3(blocks), dim3(64 * WAVES), 0, s, a, t); break;
-    }
+    if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK>), grid, dim3(64 * WAVES), 0, s, a, t);
+    else         hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC>), grid, dim3(64 * WAVES), 0, s, a, t);
 }
 
-hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, int grid_mapped, hipStream_t s) {
+hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
-    bool narrow = t.n_nodes <= 65536u;
-#ifdef RT_TRI_DEV_ENV
-    if (const char* e = getenv("RT355_TRI_STK32")) narrow = narrow && atoi(e) == 0;
-#endif
-    if (narrow) launch_tri<uint16_t>(a, t, heatmap, grid_mapped, s);
-    else        launch_tri<uint32_t>(a, t, heatmap, grid_mapped, s);
+    if (t.n_nodes <= 65536u) launch_tri<uint16_t, 4>(a, t, heatmap, s);
+    else                     launch_tri<uint32_t, 3>(a, t, heatmap, s);      // 44 KB of stacks: three workgroups per CU
     return hipGetLastError();
 }
