@@ -263,6 +263,12 @@ def main():
         kms += st["batch_kernel_ms"]; gms += st["batch_gather_ms"]; frames += st["batch_frames"]
         return elapsed, kms, gms, frames      # (serial: every rt_wait is a batch of one; the caller samples instead)
 
+    # Prime every stream and buffer set the library rotates over (the first frame on a stream pays for its
+    # hardware queue, the first gather on a buffer set for RCCL's and the runtime's lazy set-up: 7 ms that a
+    # warm-up shorter than the rotation would leave inside the timed region), then the W warm-up steps.
+    for _ in range(2 * FLIGHT):
+        step(False)
+    fence()
     for _ in range(a.warmup):
         step(a.serial)
     elapsed, kms, gms, kframes = timed(a.steps, a.serial)
@@ -390,7 +396,10 @@ def main():
                 roof.update({"achieved": ach, "frac": ach / PEAK_L2_GBPS, "gather_bytes_per_launch": gbytes,
                              "gathers_per_ray": cpu["per_ray"],
                              "basis": "achieved = (32 B x node loads + 160 B x triangle tests + 80 B x instance records) per ray, counted by "
-                                      "the oracle on the sampled tiles of this frame, x rays per launch / time_ms; peak = aggregate L2 bandwidth"})
+                                      "the oracle on the sampled tiles of this frame, x rays per launch / time_ms; peak = aggregate L2 bandwidth. "
+                                      "The bytes are what the lanes REQUEST: lanes of a wave that read the same node are served by one "
+                                      "L1 line, so this is an upper bound of the L2 traffic (frac near 1 means the request stream, not L2, "
+                                      "is saturated); `valu` is the executed-instruction fraction of the same launch"})
             else:
                 roof.update({"achieved": None, "frac": None, "basis": "gather counts come from the cpu_baseline leg (--no-cpu-baseline given)"})
             check = {"sampled_tiles_match_oracle": cpu["gpu_rows_match"]} if cpu is not None else None
