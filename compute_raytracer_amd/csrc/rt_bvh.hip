@@ -68,9 +68,6 @@
 #ifndef RT_BVH_TAIL_SMALL
 #define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres) */
 #endif
-#ifndef RT_BVH_HELP
-#define RT_BVH_HELP 1          /* end of a frame: the next reflection ray runs on an idle lane beside the shadow ray (bvh_pixels) */
-#endif
 #ifndef RT_BVH_TAIL_SERIAL
 #define RT_BVH_TAIL_SERIAL 12  /* ... when one frame has the chip to itself */
 #endif
@@ -388,10 +385,7 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
 // chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
 // workgroups serve scenes whose nodes leave room for one workgroup per CU only (4 waves per SIMD).
 // FLAT: compiled for a one-colour 1x1 sky (A.sky_flat; C1-C4) -- no cube filtering code in the kernel.
-// ENDGAME: compiled with the helper lanes of the end of a frame (below); chosen for frames that have the chip to
-// themselves -- with frames in flight the end of one frame is hidden behind the next, and the extra live state
-// costs the steady state six spilled VGPRs (1.91 -> 1.95 ms per C3 frame in flight).
-template <int WAVES, bool SGN, bool NLDS, int CAP, bool FLAT, bool ENDGAME>
+template <int WAVES, bool SGN, bool NLDS, int CAP, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
@@ -415,8 +409,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
         }
     const float4* R = NLDS ? sR : A.bvh_rec;
     const uint32_t* L = NLDS ? sL : A.bvh_link;
-    constexpr bool HELP = RT_BVH_HELP && ENDGAME && NLDS && WAVES == 8;
-    constexpr uint32_t kHas = 0x100u, kAwait = 0x200u, kHelper = 0x400u, kDone = 0x800u;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* slot = lists + wave * (uint32_t)(CAP * 64) + lane;
     // per wave: 64 x (t bits, sphere index), the running nearest hits of the pooled literal evaluation (trace_bvh: drain)
@@ -450,7 +442,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
     v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(1, 1, 1), fog = V(0, 0, 0);
     v3 normal = V(0, 0, 1), sdir = V(0, 0, 1), albedo = V(0, 0, 0);
     float dist = 0.0f, affect = 1.0f, sum = 0.0f, distance = 1.0f;
-    uint32_t link = 0;           // helper lanes at the end of a frame (below): partner lane | kHas / kAwait (owner) | kHelper / kDone (helper)
     uint32_t node = n;           // position of the lane's current ray in the node array; n: none
     float t = 9999.0f;           // nearest hit of the current ray so far (RK:172)
     int idx = -1;
@@ -520,26 +511,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
 
         bool finished = active && sc.bounces == 0u;
         bool missed = false;
-        bool adopt = false, started_shadow = false;
         const bool walking = node != n;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
         trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
+        if (walking && node == n) {
 #else
         trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
-#endif
-        bool complete = walking && node == n;                            // this lane's ray is complete
-        // Pass 0 serves the lanes whose ray is complete.  Pass 1 (end of a frame only, see below): owners that have
-        // just blended a bounce and whose helper has the next reflection ray ready take its (t, idx) and go on at once.
-        for (uint32_t pass = 0;; ++pass) {
-        if (HELP && complete && (link & kHelper) != 0u) {                // a helper's ray: its owner will fetch (t, idx)
-#ifndef RT_BVH_COUNT
+        if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
-#endif
-            link |= kDone;
-        } else if (complete || adopt) {
-#ifndef RT_BVH_COUNT
-            if (!adopt) ++nrays;
 #endif
             const float next = affect + sum;                             // RK:120
             if (!shadow) {
@@ -566,7 +546,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                     distance = length(sdir);                                 // RK:148
                     shadow = true;                                           // RK:153 next
                     node = 0u; t = 9999.0f; idx = -1;                        // shadow ray
-                    started_shadow = true;
                 }
             } else {
                 const float intensity = light_term(sc, ro, normal, sdir, distance, idx >= 0, t);
@@ -577,59 +556,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(con
                 ++bounce;
                 shadow = false;
                 finished = bounce >= sc.bounces;                             // RK:113
-                if (HELP && (link & kHas) != 0u) link = (link & 63u) | kAwait;   // the next reflection ray is already under way on the helper
-                else if (!finished) { node = 0u; t = 9999.0f; idx = -1; }    // next reflection ray
-            }
-        }
-        if (!(HELP && exhausted) || pass == 1u) break;
-        if (__ballot((link & kAwait) != 0u) == 0ull) break;
-        {
-            const int partner = (int)(link & 63u);
-            const uint32_t plink = (uint32_t)__shfl((int)link, partner, 64);
-            const float pt = __shfl(t, partner, 64);
-            const int pidx = __shfl(idx, partner, 64);
-            adopt = (link & kAwait) != 0u && (plink & kDone) != 0u;
-            if (adopt) { t = pt; idx = pidx; link = 0u; }
-            const uint32_t olink = (uint32_t)__shfl((int)link, partner, 64);      // after the adoptions
-            if ((link & kDone) != 0u && olink == 0u) link = 0u;                   // the helper is free again
-        }
-        complete = false;
-        if (__ballot(adopt) == 0ull) break;
-        }
-        if (HELP && exhausted) {
-            // ---- the frame's pixels are handed out: idle lanes take the NEXT reflection ray of a path ----
-            // A path is a chain of dependent rays, and at the end of a frame the chip waits for the longest
-            // chains, mostly empty waves carrying them.  The shadow ray of a bounce (RK:153) and the reflection
-            // ray of the next (RK:114) both start at the hit point and depend on nothing else: the lane that
-            // owns the path walks the shadow ray while an idle lane of the wave (the helper) walks the
-            // reflection ray; when the owner has blended the bounce it adopts the helper's (t, idx) instead
-            // of tracing -- the chain per bounce is the longer of the two rays, not their sum.  No speculation:
-            // the reflection ray is only handed out when the bounce limit lets the path go on.
-            const bool want = started_shadow && bounce + 1u < sc.bounces;
-            const uint64_t wants = __ballot(want), frees = __ballot(!active && !finished && link == 0u);
-            if (wants != 0ull && frees != 0ull) {
-                uint32_t* const pad = reinterpret_cast<uint32_t*>(best);      // 128 words, unused outside trace_bvh
-                const uint64_t below = (1ull << lane) - 1ull;
-                const uint32_t rw = (uint32_t)__popcll(wants & below), rf = (uint32_t)__popcll(frees & below);
-                const bool is_free = !active && !finished && link == 0u;
-                if (want) pad[64u + rw] = lane;
-                if (is_free) pad[rf] = lane;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const bool got = want && rw < (uint32_t)__popcll(frees);
-                const bool helps = is_free && rf < (uint32_t)__popcll(wants);
-                uint32_t partner = lane;
-                if (got) partner = pad[rw];
-                if (helps) partner = pad[64u + rf];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const v3 po = V(__shfl(ro.x, (int)partner, 64), __shfl(ro.y, (int)partner, 64), __shfl(ro.z, (int)partner, 64));
-                const v3 pd = V(__shfl(rd.x, (int)partner, 64), __shfl(rd.y, (int)partner, 64), __shfl(rd.z, (int)partner, 64));
-                if (got) link = partner | kHas;
-                if (helps) {
-                    link = partner | kHelper;
-                    ro = po; rd = pd;
-                    shadow = false;
-                    node = 0u; t = 9999.0f; idx = -1;
-                }
+                if (!finished) { node = 0u; t = 9999.0f; idx = -1; }         // next reflection ray
             }
         }
         if (finished) {
@@ -703,10 +630,7 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_TAIL")) a.bvh_tail = (uint32_t)atoi(e);
 #endif
-    constexpr bool kEnd = RT_BVH_HELP && NLDS && WAVES == 8;       // the only form that has an end-game variant
-    const bool endgame = kEnd && a.grid_share <= 1u;
-    auto k = a.sky_flat ? (endgame ? bvh_pixels<WAVES, SGN, NLDS, CAP, true, kEnd> : bvh_pixels<WAVES, SGN, NLDS, CAP, true, false>)
-                        : (endgame ? bvh_pixels<WAVES, SGN, NLDS, CAP, false, kEnd> : bvh_pixels<WAVES, SGN, NLDS, CAP, false, false>);
+    auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, true> : bvh_pixels<WAVES, SGN, NLDS, CAP, false>;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
