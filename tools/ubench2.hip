@@ -50,6 +50,25 @@ KERNEL(k_sub_s, "v_sub_f32 %0, %3, %0")
 KERNEL(k_mul_s, "v_mul_f32 %0, %3, %0")
 KERNEL(k_fma_s, "v_fma_f32 %0, %1, %3, %0")
 KERNEL(k_fma_inl, "v_fma_f32 %0, %1, 2.0, %0")
+KERNEL(k_add_e64, "v_add_f32_e64 %0, %1, %0")
+KERNEL(k_mul_e64, "v_mul_f32_e64 %0, %1, %0")
+KERNEL(k_sub_vv, "v_sub_f32 %0, %1, %0")
+KERNEL(k_fma_one, "v_fma_f32 %0, %1, 1.0, %0")
+KERNEL(k_fma_mone, "v_fma_f32 %0, %0, -1.0, %1")
+KERNEL(k_fma_mul, "v_fma_f32 %0, %1, %0, -%2")
+KERNEL(k_max_e64, "v_max_f32_e64 %0, %1, %0")
+KERNEL(k_fmac_e64, "v_fmac_f32_e64 %0, %1, %2")
+KERNEL(k_mov_e64, "v_mov_b32_e64 %0, %1")
+KERNEL(k_cnd_e64, "v_cndmask_b32_e64 %0, %1, %0, vcc")
+KERNEL(k_cmp_e64, "v_cmp_lt_f32_e64 vcc, %1, %0")
+KERNEL(k_addu_e32, "v_add_u32_e32 %0, %1, %0")
+KERNEL(k_addu_e64, "v_add_u32_e64 %0, %1, %0")
+KERNEL(k_lshl_e32, "v_lshlrev_b32_e32 %0, 1, %0")
+KERNEL(k_lshl_e64, "v_lshlrev_b32_e64 %0, 1, %0")
+KERNEL(k_and_e32, "v_and_b32_e32 %0, %1, %0")
+KERNEL(k_and_e64, "v_and_b32_e64 %0, %1, %0")
+KERNEL(k_rcp_e64, "v_rcp_f32_e64 %0, %0")
+KERNEL(k_lshladd, "v_lshl_add_u32 %0, %1, 2, %0")
 KERNEL(k_max, "v_max_f32 %0, %1, %0")
 KERNEL(k_max3, "v_max3_f32 %0, %1, %2, %0")
 KERNEL(k_cmp_vcc, "v_cmp_lt_f32 vcc, %1, %0")
@@ -93,7 +112,12 @@ int main() {
     Entry entries[] = {
         {"v_add_f32 v,v", k_add}, {"v_mul_f32 v,v", k_mul}, {"v_fmac_f32 v,v", k_fmac}, {"v_fma_f32 v,v,v", k_fma},
         {"v_fma_f32 v,v,-v", k_fma_neg}, {"v_sub_f32 s,v", k_sub_s}, {"v_mul_f32 s,v", k_mul_s},
-        {"v_fma_f32 v,s,v", k_fma_s}, {"v_fma_f32 v,2.0,v", k_fma_inl}, {"v_max_f32", k_max}, {"v_max3_f32", k_max3},
+        {"v_fma_f32 v,s,v", k_fma_s}, {"v_fma_f32 v,2.0,v", k_fma_inl}, {"v_add_f32_e64", k_add_e64}, {"v_mul_f32_e64", k_mul_e64}, {"v_sub_f32 v,v", k_sub_vv},
+        {"v_max_f32_e64", k_max_e64}, {"v_fmac_f32_e64", k_fmac_e64}, {"v_mov_b32_e64 v", k_mov_e64}, {"v_cndmask_e64 vcc", k_cnd_e64},
+        {"v_cmp_lt_e64 vcc", k_cmp_e64}, {"v_add_u32_e32", k_addu_e32}, {"v_add_u32_e64", k_addu_e64}, {"v_lshlrev_e32", k_lshl_e32},
+        {"v_lshlrev_e64", k_lshl_e64}, {"v_and_b32_e32", k_and_e32}, {"v_and_b32_e64", k_and_e64}, {"v_rcp_f32_e64", k_rcp_e64},
+        {"v_lshl_add_u32", k_lshladd},
+        {"fma v,1.0,v (=add)", k_fma_one}, {"fma v,-1.0,v (=sub)", k_fma_mone}, {"fma v,v,-v0 (=mul)", k_fma_mul}, {"v_max_f32", k_max}, {"v_max3_f32", k_max3},
         {"v_cmp_lt vcc", k_cmp_vcc}, {"v_cmp_lt sgpr", k_cmp_s}, {"v_cndmask vcc", k_cndmask}, {"v_mov_b32 s", k_mov_s},
         {"v_mov_b32 v", k_mov_v}, {"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt}, {"v_add_f32_dpp", k_add_dpp},
         {"v_readlane_b32", k_readlane}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_add_f32", k_pk_add}, {"v_pk_mul_f32", k_pk_mul},
