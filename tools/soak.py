@@ -1,12 +1,19 @@
-"""Soak test (development): many frames, every read-back hashed against the golden C3 frame."""
+"""Soak test (development): many frames, every read-back hashed against the golden C3 frame; with `sky` as second
+argument the synthetic 6 x 512^2 sky (bvh_pixels records + sky_resolve), hashed against the first frame.
+usage: python tools/soak.py [batches=150] [sky]"""
 import os, sys, json, hashlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import compute_raytracer_amd as rt
 meta = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "frames.json")))["C3"]
 cfg = rt.BASELINE_CONFIGS["C3"]
 scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
-r = rt.RendererRaytracing(cfg["width"], cfg["height"], scene, maxBounces=cfg["bounces"]).initialize()
+textured = len(sys.argv) > 2 and sys.argv[2] == "sky"
+r = rt.RendererRaytracing(cfg["width"], cfg["height"], scene, maxBounces=cfg["bounces"]).initialize(
+    rt.CubemapMaterial.synthetic_daylight() if textured else None)
 r.recalculateScene()
+if textured:
+    r.render()
+    meta = {"sha256": hashlib.sha256(r.read_pixels().tobytes()).hexdigest(), "rays": r.stats()["rays"]}
 bad = 0; t0 = time.time(); frames = 0
 for batch in range(int(sys.argv[1]) if len(sys.argv) > 1 else 150):
     n = 1 + (batch * 7) % 23
