@@ -1,0 +1,40 @@
+"""One-off differential run (development): random procedural triangle scenes through trace_triangles and the
+heatmap kernel against the CPU oracle -- instance counts, tessellations, cameras, skies, bounce limits, frame sizes.
+usage: python tools/diff_run_tri.py [scenes=120] [first seed=7000]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import compute_raytracer_amd as rt
+from compute_raytracer_amd.procedural import triangle_scene, tri_buffers
+from oracle import rt_oracle_py as oracle
+from helpers import gpu_render_tri, diff_stats
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
+bad, rays_total, t0 = 0, 0, time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    scene, mat = triangle_scene(seed=seed, n_models=int(rng.integers(1, 7)), rings=int(rng.integers(3, 14)), sectors=int(rng.integers(4, 18)))
+    scene.update(float(rng.uniform(0, 3)))
+    scene.camera.position = [float(rng.uniform(-3, 3)), float(rng.uniform(0.3, 5)), float(rng.uniform(0, 5))]
+    scene.camera.eulers = np.array([270.0 + rng.uniform(-40, 40), 95.0 + rng.uniform(-30, 40)], np.float32)
+    scene.camera.update()
+    scene.light.position = [float(rng.uniform(-4, 4)), float(rng.uniform(2, 8)), float(rng.uniform(-8, 2))]
+    m = int(rng.choice([1, 1, 3, 8]))
+    sky = rt.CubemapMaterial()
+    sky.faces = [rng.integers(0, 256, (m, m, 4), dtype=np.uint8) for _ in range(6)]
+    W, H, B = int(rng.integers(24, 200)), int(rng.integers(16, 130)), int(rng.choice([0, 1, 2, 4, 6]))
+    bufs = tri_buffers(scene, mat)
+    ref, _, rays = oracle.render_tri(scene.pack_params(B), bufs, sky.faces, W, H)
+    img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky)
+    href, _ = oracle.heatmap_tri(scene.pack_params(B), bufs, W, H)
+    himg, _ = gpu_render_tri(scene, mat, W, H, B, skybox=sky, heatmap=True)
+    ok = np.array_equal(img, ref) and st["rays"] == rays and np.array_equal(himg, href)
+    rays_total += rays
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, W, H, B, len(scene.triangles), diff_stats(img, ref), diff_stats(himg, href), flush=True)
+    if (seed - first) % 20 == 19:
+        print("... %d scenes, %d mismatches, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
+print("diff_run_tri: %d scenes (seeds %d..%d), %d rays, mismatches %d, %.0f s" % (count, first, first + count - 1, rays_total, bad, time.time() - t0))
