@@ -112,7 +112,12 @@ int rt_write_params(rt_ctx* ctx, const float params[24]);
 int rt_write_spheres(rt_ctx* ctx, const float* records, uint32_t n);
 
 /* Replaces copyExternalImageToTexture(face i) (CM:73-77).  face order as CM:40-47:
- * 0 +X, 1 -X, 2 +Y, 3 -Y, 4 +Z, 5 -Z; rgba8unorm, w*h*4 bytes, row 0 = top. */
+ * 0 +X, 1 -X, 2 +Y, 3 -Y, 4 +Z, 5 -Z; rgba8unorm, w*h*4 bytes, row 0 = top.  Six equal squares
+ * are a WebGPU cube texture and filter seamlessly across edges; other image sets clamp per image.
+ * Memory: a sphere scene rendered through the hierarchy kernel under a sky that is not one colour
+ * keeps 32 bytes per local pixel of end-of-path records in each of four frame slots (the sky is
+ * sampled by a second kernel): 1.06 GB per slot at 7680x4320, allocated when a
+ * frame first needs them. */
 int rt_write_cubemap_face(rt_ctx* ctx, int face, uint32_t w, uint32_t h, const uint8_t* rgba);
 
 /* The reference's live scene type: triangles behind a two-level BVH (RK:168-410).  Same byte
