@@ -170,6 +170,12 @@ def golden_frame(name):
 
 def main():
     a = parse()
+    # stdout carries ONE line, the JSON.  Libraries print banners there from native code (gloo: "[Gloo] Rank 0 is
+    # connected ...", RCCL: its version block at the first communicator), so file descriptor 1 points at stderr
+    # until the line is ready.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -432,7 +438,10 @@ def main():
             out["gather_ms_avg"] = gather_ms
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)                     # whatever the teardown prints goes to stderr again
 
     r.close()
     if multi:

@@ -18,8 +18,10 @@ def run_bench(*args, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), cwd=ROOT, env=e,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    return json.loads(line), out.stderr
+    lines = out.stdout.splitlines()
+    # the contract: ONE line on stdout (native banners of gloo / RCCL included -- bench.py keeps them on stderr)
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[:2000]
+    return json.loads(lines[0]), out.stderr
 
 
 def test_bench_json_contract():
