@@ -221,7 +221,9 @@ struct SceneLds {
 // GS          : "global scene": nothing is staged, the records are read from global memory (L2)
 //               with wave-uniform addresses.  The fallback for scenes too large for a CU's LDS
 //               (> 4608 spheres); the per-wave candidate lists still live in LDS.
-template <int WAVES, bool FILTER, bool FIRST, bool SGN, bool W_LDS, int CAP, bool GS = false>
+// FLAT (all three pixel kernels): compiled for a one-colour 1x1 sky (A.sky_flat; the launch wrappers choose) -- the
+// seamless cube filter is not instantiated, and its registers are not paid for inside the sphere loops.
+template <int WAVES, bool FILTER, bool FIRST, bool SGN, bool W_LDS, int CAP, bool GS = false, bool FLAT = false>
 __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t N = A.N, N16 = A.N16;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) 
         if (bounce == 0) dist = hit ? t : 0.0f;                  // RK:116-118 (zero-initialised state)
         const float next = affect + sum;                         // RK:120
         if (!hit) {                                              // RK:122-126
-            const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
+            const v3 sky = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, rd));
             color = divs(add(scale(sum, color), scale(affect, sky)), next);
             alive = false;
             break;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) 
             }
         }
     }
-    if (!cont) reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, dir0, color, dist);   // RK:91-98
+    if (!cont) reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel_sky(scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, dir0)), color, dist);   // RK:91-98
     count_rays(A.rays, nrays);
 }
 
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(64 * WAVES) void trace_pixels(const RtFrameArgs A) 
 // (x, y) and (x+8, y), and runs the primary rays and then the shadow rays of both pixels through
 // trace_hoisted_pair.  Pixels whose path ends at bounce 0 (miss, or maxBounces == 1) are written;
 // the others are appended to the path queue for trace_paths.
-template <int WAVES, bool SGN, bool W_LDS, int CAP>
+template <int WAVES, bool SGN, bool W_LDS, int CAP, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES, 4) void first_bounce(const RtFrameArgs A) {   // 4 waves/SIMD: <= 128 VGPRs
     extern __shared__ float4 lds[];
     const uint32_t N16 = A.N16;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void first_bounce(const RtFrameArgs 
                 hit[j] = idx[j] >= 0;
                 dist[j] = hit[j] ? t[j] : 0.0f;                                    // RK:116-118
                 if (!hit[j]) {                                                     // RK:122-126, next = 1 + 0
-                    const v3 sky = scale(sc.minIntensity, cube_sample(A, rd[j]));
+                    const v3 sky = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, rd[j]));
                     color[j] = divs(add(scale(0.0f, color[j]), scale(1.0f, sky)), 1.0f);
                 } else {
                     const float4 g = A.geo[idx[j]];
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void first_bounce(const RtFrameArgs 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             if (in[j] && !cont[j])
-                reinterpret_cast<uint32_t*>(A.out)[opix[j]] = compose_pixel(A, sc, dir0[j], color[j], dist[j]);   // RK:91-98
+                reinterpret_cast<uint32_t*>(A.out)[opix[j]] = compose_pixel_sky(scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, dir0[j])), color[j], dist[j]);   // RK:91-98
     }
     count_rays(A.rays, nrays);
 }
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void first_bounce(const RtFrameArgs 
 // Entries are popped in chunks of 64 with one atomicAdd per chunk; neighbouring entries come
 // from the same 8x8 tile of the first stage.  There is no inter-workgroup dependency: a
 // workgroup that finds the queue empty exits.
-template <int WAVES, bool SGN, bool W_LDS, int CAP>
+template <int WAVES, bool SGN, bool W_LDS, int CAP, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES) void trace_paths(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t N16 = A.N16;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(64 * WAVES) void trace_paths(const RtFrameArgs A) {
             ++nrays;
             const float next = affect + sum;                         // RK:120
             if (idx < 0) {                                           // RK:122-126
-                const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
+                const v3 sky = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, rd));
                 color = divs(add(scale(sum, color), scale(affect, sky)), next);
                 finished = true;
             } else {
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(64 * WAVES) void trace_paths(const RtFrameArgs A) {
             const uint32_t orow = opix / A.W, x = opix - orow * A.W;
             const uint32_t y = (A.tile_first + (orow >> 3) * A.tile_step) * 8u + (orow & 7u);
             const v3 dir0 = primary_dir(A, sc, x, y);
-            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, dir0, color, dist);
+            reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel_sky(scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, dir0)), color, dist);
             active = false;
         }
     }
@@ -634,7 +636,7 @@ hipError_t launch_pixels(const RtFrameArgs& a, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
     const size_t lds = GS ? (FILTER ? (size_t)WAVES * CAP * 256u : 0u) : lds_pixels<WAVES, FILTER, FIRST, W_LDS, CAP>(a);
     if (lds > kLdsCap) return hipErrorInvalidValue;
-    auto k = trace_pixels<WAVES, FILTER, FIRST, SGN, W_LDS, CAP, GS>;
+    auto k = a.sky_flat ? trace_pixels<WAVES, FILTER, FIRST, SGN, W_LDS, CAP, GS, true> : trace_pixels<WAVES, FILTER, FIRST, SGN, W_LDS, CAP, GS, false>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
     dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
@@ -652,7 +654,7 @@ hipError_t launch_paths(const RtFrameArgs& a, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
     const size_t lds = lds_paths<WAVES, W_LDS, CAP>(a);
     if (lds > kLdsCap) return hipErrorInvalidValue;
-    auto k = trace_paths<WAVES, SGN, W_LDS, CAP>;
+    auto k = a.sky_flat ? trace_paths<WAVES, SGN, W_LDS, CAP, true> : trace_paths<WAVES, SGN, W_LDS, CAP, false>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
     // persistent grid: enough workgroups to fill 256 CUs at the residency LDS allows;
@@ -676,7 +678,7 @@ hipError_t launch_first(const RtFrameArgs& a, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
     const size_t lds = lds_first<WAVES, W_LDS, CAP>(a);
     if (lds > kLdsCap) return hipErrorInvalidValue;
-    auto k = first_bounce<WAVES, SGN, W_LDS, CAP>;
+    auto k = a.sky_flat ? first_bounce<WAVES, SGN, W_LDS, CAP, true> : first_bounce<WAVES, SGN, W_LDS, CAP, false>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
     const uint32_t per_cu = (uint32_t)min((size_t)(32 / WAVES), kLdsCap / lds);

@@ -277,7 +277,8 @@ __device__ inline v3 tex2d_sample(const RtTriScene& T, float u, float v) {
 }
 
 // ---- kernel: RK main over the triangle scene ---------------------------------------------------------
-template <int WAVES, typename STK, int OCC>
+// FLAT: compiled for a one-colour 1x1 sky (A.sky_flat) -- no cube filtering code inside the traversal's register budget.
+template <int WAVES, typename STK, int OCC, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
     __shared__ STK stacks[2 * kStack * 64 * WAVES];
     STK* tstack = stacks + threadIdx.x;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
         if (bounce == 0) dist = hit ? h.t : 0.0f;                                    // RK:116-118
         const float next = affect + sum;                                             // RK:120
         if (!hit) {                                                                  // RK:122-126
-            const v3 sky = scale(sc.minIntensity, cube_sample(A, rd));
+            const v3 sky = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, rd));
             color = divs(add(scale(sum, color), scale(affect, sky)), next);
             break;
         }
@@ -333,7 +334,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;
     // the fog colour is the sky along the primary ray (RK:93-96): its direction is formed again here rather than
     // carried through both traversals
-    reinterpret_cast<uint32_t*>(A.out)[opix] = compose_pixel(A, sc, primary_dir(A, sc, x, y), color, dist);   // RK:91-98
+    reinterpret_cast<uint32_t*>(A.out)[opix] =
+        compose_pixel_sky(scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, primary_dir(A, sc, x, y))), color, dist);   // RK:91-98
     count_rays(A.rays, nrays);
 }
 
@@ -375,7 +377,8 @@ template <typename STK, int OCC, int WAVES = 1>
 static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
     dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
     if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK>), grid, dim3(64 * WAVES), 0, s, a, t);
-    else         hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC>), grid, dim3(64 * WAVES), 0, s, a, t);
+    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true>), grid, dim3(64 * WAVES), 0, s, a, t);
+    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false>), grid, dim3(64 * WAVES), 0, s, a, t);
 }
 
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
