@@ -9,7 +9,8 @@ from compute_raytracer_amd.procedural import triangle_scene
 label = sys.argv[1] if len(sys.argv) > 1 else ""
 scene, mat = triangle_scene(seed=21, n_models=2, rings=48, sectors=64)
 for w, h in ((1344, 846), (3840, 2160)):
-    r = rt.RendererRaytracing(w, h, scene, maxBounces=4).initialize(None, mat)
+    sky = rt.CubemapMaterial.synthetic_daylight() if os.environ.get("RT355_PROBE_SKY") else None
+    r = rt.RendererRaytracing(w, h, scene, maxBounces=4).initialize(sky, mat)
     ms = []
     for _ in range(10):
         r.render(); ms.append(r.stats()["kernel_ms"])
