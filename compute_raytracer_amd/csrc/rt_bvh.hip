@@ -8,16 +8,17 @@
 //     scene's spheres and stores it in depth-first order with skip links ("threaded" tree): a
 //     ray walks the array front to back, `i = pass ? i + 1 : skip[i]`, no stack;
 //   * an inner node is tested with the same conservative discriminant filter as a sphere
-//     (rt_filter.h: 8 v_fma_f32 + v_min_f32 + v_cmp), on a record of the same layout
+//     (rt_filter.h: 8 v_fma_f32, one of them clamping, + v_cmp; trace_bvh below), on a record of the same layout
 //     {C * 2^40, (|C|^2 (1-eps) - R^2 (1+kappa)) * 2^80}; its radius R covers every member sphere
 //     with the slack derived below, so a node can only be skipped when no member can be hit;
 //   * a leaf is one sphere: its record IS the filter record of rt_kernels.hip (geo_f), a lane
 //     whose ray passes it appends the sphere index to its candidate list in LDS;
-//   * after the walk every lane evaluates its candidates with the reference's literal
-//     arithmetic (exact_full) and keeps the lexicographic minimum of (t, index) -- exactly what
-//     the reference's in-order loop with `t < nearest` keeps;
+//   * after the walk the wave pools its lanes' candidates and evaluates them with the reference's literal
+//     arithmetic, full lanes, keeping per ray the lexicographic minimum of (t, index) -- exactly what
+//     the reference's in-order loop with `t < nearest` keeps (trace_bvh: drain);
 //   * nodes and links are staged in LDS (20 B per node, ~1.35 nodes per sphere); lanes read them
-//     with divergent addresses, so the kernel is bound by LDS bandwidth, not by the FMA pipe.
+//     with divergent addresses: the kernel sits where VALU issue and the latency of that dependent
+//     chain of LDS reads meet, not on the FMA pipe alone like the brute-force kernels.
 //
 // One persistent kernel renders the frame: every lane carries one path through a small state
 // machine (reflection ray -> shadow ray -> next bounce ...) and takes the next pixel from an
@@ -58,10 +59,11 @@
 
 #define RT_BVH_KAPPA 6.103515625e-05f   /* kappa_h = 2^-14: inflation of the ray direction in the walk */
 
-// Lanes still walking below which a wave suspends the walk (0: never).  Measured (tools/ab.py,
-// same box): C3 3.93 / 3.51 / 3.36 / 3.40 / 3.44 ms and C5 40.7 / 32.5 / 29.1 / 27.8 / 27.3 ms for
-// 0 / 8 / 16 / 24 / 32: the larger the scene, the longer the walk relative to the shading a
-// suspension repeats.
+// Lanes still walking below which a wave suspends the walk (0: never): a launch argument (launch_bvh_as)
+// with these defaults.  Round-1 kernel (tools/ab.py): C3 3.93 / 3.51 / 3.36 / 3.40 / 3.44 ms and C5 40.7 /
+// 32.5 / 29.1 / 27.8 / 27.3 ms for 0 / 8 / 16 / 24 / 32 -- the larger the scene, the longer the walk
+// relative to the shading a suspension repeats; today's kernel: C3 flat between 8 and 24, C5 best at 32
+// (profiles/r02/tail2.log, tail3.log, tail_c5.log).
 #ifndef RT_BVH_GRAB
 #define RT_BVH_GRAB 256u   /* pixel slots per cursor atomic: a multiple of 64 (whole tiles) */
 #endif
