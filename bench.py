@@ -62,8 +62,8 @@ FLIGHT = 4                  # frames the library keeps concurrent (rt_ctx rotate
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=None, help="BASELINE config (default C3; C4 when --gpus > 1)")
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--variant", type=int, default=0)
