@@ -2,7 +2,7 @@
 """bench.py -- the headline measurement: Mrays/s (and frames/s) of the ray-trace hot path on
 BASELINE.json's configuration C3 (3840x2160, 1024 spheres, 8 bounces), on N GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                                  (= --gpus 1 --steps 100 --warmup 5)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
