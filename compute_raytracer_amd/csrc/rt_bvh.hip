@@ -68,7 +68,7 @@
 #define RT_BVH_GRAB 256u   /* pixel slots per cursor atomic: a multiple of 64 (whole tiles) */
 #endif
 #ifndef RT_BVH_TAIL_SMALL
-#define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres) */
+#define RT_BVH_TAIL_SMALL 20   /* 8-wave workgroups (scenes up to ~1300 spheres), frames in flight: 16 / 20 / 24 = 1.864 / 1.855 / 1.861 ms (tools/tail_ab.py) */
 #endif
 #ifndef RT_BVH_TAIL_SERIAL
 #define RT_BVH_TAIL_SERIAL 12  /* ... when one frame has the chip to itself */
