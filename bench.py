@@ -358,9 +358,12 @@ def main():
                     estimated = prof is not None
             except Exception:
                 prof = None
-        valu = (prof or {}).get("executed", {}).get("valu_wave_insts_per_launch")
+        executed = (prof or {}).get("executed", {})
+        valu_serial = executed.get("valu_wave_insts_per_launch")               # PMC pass of one-frame-at-a-time launches
+        valu = executed.get("valu_wave_insts_per_launch_in_flight", valu_serial) if overlapping else valu_serial
         if valu is not None and estimated:
             valu = valu / world
+            valu_serial = valu_serial / world
         roof = {"bound": "valu-issue (fp32 vector pipe)", "kernel": label, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "kernel_ms_avg": kernel_ms, "time_ms": roof_ms,
                 "launches_in_flight": FLIGHT if overlapping else 1}
@@ -377,7 +380,7 @@ def main():
                          "time_ms = frame period with launches_in_flight frames overlapping, else the launch duration.",
             })
             if serial_ms is not None and not queue_pipeline:
-                s_ach = valu * FLOP_SLOTS_PER_VALU / (serial_ms * 1e-3) / 1e12
+                s_ach = valu_serial * FLOP_SLOTS_PER_VALU / (serial_ms * 1e-3) / 1e12
                 roof["serial"] = {"time_ms": serial_ms, "achieved": s_ach, "frac": s_ach / PEAK_FP32_TFLOPS}
         else:
             roof.update({"achieved": None, "frac": None, "traffic": None,

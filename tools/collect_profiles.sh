@@ -15,10 +15,13 @@ ARGS="--steps 12 --warmup 3 --no-cpu-baseline --serial-steps 0 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -o t -- python3 bench.py $ARGS > $OUT/${KEY}__pipelined_bench.json 2> $OUT/trace_pipelined.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -o t -- python3 bench.py $ARGS --serial > $OUT/${KEY}__serial_bench.json 2> $OUT/trace_serial.err
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o sq -- python3 bench.py $ARGS --serial > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+# the same counters for the launches of frames in flight (one workgroup per CU, their own suspension threshold): the
+# profiler serialises the dispatches, the launch configuration and with it the instruction count are those of the default run
+rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_sqflight -o sqflight -- python3 bench.py $ARGS > $OUT/pmc_sqflight.json 2> $OUT/pmc_sqflight.err
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python3 bench.py $ARGS --serial > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python3 bench.py $ARGS --serial > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 mkdir -p $OUT/collected/pmc
-for p in sq fetch write; do
+for p in sq sqflight fetch write; do
   f=$(find $OUT/pmc_$p -name "*counter_collection.csv" | head -n 1)
   [ -n "$f" ] && cp "$f" $OUT/collected/pmc/${KEY}__$p.csv
 done

@@ -90,6 +90,9 @@ def summarise(files):
             ex["valu_insts_per_simd_cycle"] = ex["valu_wave_insts_per_launch"] / (SIMDS * ex["shader_cycles_per_launch"])
             ex["valu_issue_frac"] = CYCLES_PER_VALU * ex["valu_insts_per_simd_cycle"]
             ex["sustained_clock_ghz"] = ex["shader_cycles_per_launch"] / ex["kernel_ns"]
+        fl = passes.get("sqflight", {}).get(dom)
+        if fl and "SQ_INSTS_VALU" in fl:        # the launches of frames in flight (collect_profiles.sh)
+            ex["valu_wave_insts_per_launch_in_flight"] = fl["SQ_INSTS_VALU"]
         entry["executed"] = ex
     fetch = next((p[dom]["FETCH_SIZE"] for p in passes.values() if dom in p and "FETCH_SIZE" in p[dom]), None)
     write = next((p[dom]["WRITE_SIZE"] for p in passes.values() if dom in p and "WRITE_SIZE" in p[dom]), None)
