@@ -623,9 +623,9 @@ __global__ __launch_bounds__(256) void sky_resolve(const RtFrameArgs A) {
 template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
 hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     // The walk is left for the shading pass once fewer than `tail` lanes still walk.  A frame that has the
-    // chip to itself prefers a lower threshold than frames that share it (C3: 12 vs 16 -- 2.40 -> 2.3x ms one
-    // frame at a time, but 2.08 -> 2.11 in flight): with one frame the end-of-frame tail is paid in full, and
-    // shorter trips shorten it.
+    // chip to itself prefers a lower threshold than frames that share it (C3, tools/knob_ab.py: one frame at a
+    // time 8 / 12 / 16 / 20 lanes = 2.32 / 2.27 / 2.29 / 2.31 ms; in flight 16 / 20 / 24 = 1.864 / 1.855 / 1.861):
+    // with one frame the end-of-frame tail is paid in full, and shorter trips shorten it.
     RtFrameArgs a = a0;
     a.bvh_tail = (uint32_t)TAIL;
     if (TAIL == RT_BVH_TAIL_SMALL && a.grid_share <= 1u) a.bvh_tail = RT_BVH_TAIL_SERIAL;
