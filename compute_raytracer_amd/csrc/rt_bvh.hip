@@ -629,6 +629,9 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     RtFrameArgs a = a0;
     a.bvh_tail = (uint32_t)TAIL;
     if (TAIL == RT_BVH_TAIL_SMALL && a.grid_share <= 1u) a.bvh_tail = RT_BVH_TAIL_SERIAL;
+    // small shares (a rank of eight of a 4K frame: 1 M pixels) end sooner after they begin: 12 / 16 / 20 / 24 lanes =
+    // 0.298 / 0.300 / 0.302 / 0.307 ms per frame in flight (profiles/r02/knobs_w8.log)
+    else if (TAIL == RT_BVH_TAIL_SMALL && a.n_local_tiles * 8u * a.W < (1u << 22)) a.bvh_tail = 16u;
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_TAIL")) a.bvh_tail = (uint32_t)atoi(e);
 #endif

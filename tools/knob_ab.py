@@ -1,13 +1,14 @@
 """Development probe for last-half-per-cent knobs of bvh_pixels: C3, 64-frame batches in flight (min of 5; repeatable
 to about a microsecond) and, with `serial` as argument, 40 single frames (kernel time, min and median).
-usage: [RT355_LIB=tools/bin/librt355_dev.so RT355_BVH_TAIL=.. RT355_BVH_BLOCKS=..] python tools/knob_ab.py [serial] [label]"""
+usage: [KNOB_WORLD=8] [RT355_LIB=tools/bin/librt355_dev.so RT355_BVH_TAIL=.. RT355_BVH_BLOCKS=..] python tools/knob_ab.py [serial] [label]"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import compute_raytracer_amd as rt
 cfg = rt.BASELINE_CONFIGS["C3"]
 scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
-r = rt.RendererRaytracing(cfg["width"], cfg["height"], scene, maxBounces=cfg["bounces"]).initialize()
+world = int(os.environ.get("KNOB_WORLD", "1"))            # the share of rank 0 of `world` ranks
+r = rt.RendererRaytracing(cfg["width"], cfg["height"], scene, maxBounces=cfg["bounces"], rank=0, world=world).initialize()
 r.recalculateScene()
 for _ in range(8): r.enqueue()
 r.wait()
