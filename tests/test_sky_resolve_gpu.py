@@ -99,3 +99,24 @@ def test_partitions_and_resize_under_a_textured_sky(oracle):
         ref = oracle_render(oracle, scene, W, H, B, skybox=sky)[0]
         assert np.array_equal(r.read_pixels(), ref), (W, H)
     r.close()
+
+
+def test_gather_path_under_a_textured_sky(oracle):
+    """rt_render_gather (communicator of one): render + sky_resolve + exchange + de-interleave on the rotating
+    streams, six frames in flight with different cameras; the assembled frame is the oracle's."""
+    sky = textured(11, 8)
+    scene = rt.SceneRaytracing().createScene(synthetic_spheres(220, 5))
+    W, H, B = 176, 99, 4
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky)
+    r.set_variant(BVH)
+    r.comm_init(rt.RendererRaytracing.comm_unique_id(), 0, 1)
+    try:
+        for root in (0, -1):
+            for f in range(6):
+                move(scene, f)
+                r.recalculateScene()
+                r.render_gather(root)
+            ref = oracle_render(oracle, scene, W, H, B, skybox=sky)[0]
+            assert np.array_equal(r.read_frame(), ref), root
+    finally:
+        r.close()
