@@ -147,8 +147,8 @@ def cpu_baseline_tri(cfg, scene, mat, sky, target_s, gpu_frame):
     }
 
 
-def kernel_label(mode, variant, N):
-    hierarchy = mode == "fast" and (variant == 4 or (variant == 0 and N >= 128))
+def kernel_label(mode, variant, N, serial=False):
+    hierarchy = mode == "fast" and (variant == 4 or (variant == 0 and N >= (128 if serial else 72)))    # rt_api.hip: bvh_from
     queue_pipeline = mode == "fast" and not hierarchy and (variant in (2, 3) or (variant in (0, 4, 5) and N >= 320))
     if mode == "strict":
         return "trace_pixels<FILTER=false> (literal loop)", hierarchy, queue_pipeline
@@ -329,7 +329,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = rays_frame * a.steps / elapsed / 1e6
-        label, hierarchy, queue_pipeline = kernel_label(a.mode, a.variant, N)
+        label, hierarchy, queue_pipeline = kernel_label(a.mode, a.variant, N, a.serial)
         if tri:
             label, hierarchy, queue_pipeline = "trace_triangles (TLAS/BLAS traversal, pixel per lane, one 8x8 tile per single-wave workgroup)", False, False
         # launches of consecutive frames overlap on the device (each on a share of the chip): the chip-level

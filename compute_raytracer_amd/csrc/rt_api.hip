@@ -486,11 +486,14 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     bool filter_ok = false;
     uint32_t signed_filter = 0;
     rt_plan(c->scene_bound, c->scene_min_radius, c->params, filter_ok, signed_filter);
-    // Fast mode renders through the bounding-sphere hierarchy (rt_bvh.hip) from 128 spheres on
-    // (default, variant 0; measured crossover against the brute-force kernels ~100 spheres) or
-    // whenever variant 4 asks for it; variant 5 is the brute-force default, 1-3 its forms.
+    // Fast mode renders through the bounding-sphere hierarchy (rt_bvh.hip) from 128 spheres on (default,
+    // variant 0) -- from 72 on for a caller that keeps frames in flight, where the hierarchy kernel's
+    // end-of-frame tail is hidden: at 3840x2160 / 8 bounces the two forms cross at ~110 spheres one frame at a
+    // time and at ~60 in flight (96 spheres: 1.33 vs 1.00 ms and 0.76 vs 0.98 ms; profiles/r02/count_sweep.log) --
+    // or whenever variant 4 asks for it; variant 5 is the brute-force default, 1-3 its forms.
+    const uint32_t bvh_from = c->pipelined_hint ? 72u : 128u;
     const bool use_bvh = !tri && c->mode == RT_MODE_FAST && filter_ok && c->n > 0 &&
-                         (c->variant == 4 || (c->variant == 0 && c->n >= 128u));
+                         (c->variant == 4 || (c->variant == 0 && c->n >= bvh_from));
     // Frames in flight: the hierarchy kernel and the triangle kernels write nothing but their
     // own control block and `dst`, so consecutive frames may overlap on the device (the next
     // frame's workgroups start while the last paths of this one finish), and so may the

@@ -141,7 +141,8 @@ int rt_select_kernel(rt_ctx* ctx, int kernel);
 int rt_set_mode(rt_ctx* ctx, int mode);
 
 /* Kernel variant for A/B measurements (0 = library default).  Fast-mode sphere scenes:
- * 0 = bounding-sphere hierarchy from 128 spheres on, single brute-force kernel below;
+ * 0 = bounding-sphere hierarchy from 128 spheres on (from 72 on once the caller keeps frames in flight), single
+ * brute-force kernel below;
  * 4 = hierarchy for any sphere count; 5 = brute force (two-kernel pipeline from 320 spheres on);
  * 1, 2, 3 = individual brute-force forms.  Every variant produces the same pixels.  See DESIGN.md. */
 int rt_set_variant(rt_ctx* ctx, int variant);
