@@ -388,7 +388,7 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
 // workgroups serve scenes whose nodes leave room for one workgroup per CU only (4 waves per SIMD).
 // FLAT: compiled for a one-colour 1x1 sky (A.sky_flat; C1-C4) -- no cube filtering code in the kernel.
 template <int WAVES, bool SGN, bool NLDS, int CAP, bool FLAT>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 6 : 4) void bvh_pixels(const RtFrameArgs A) {
+__global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
     const uint32_t n4 = (n + 4u) & ~3u;
@@ -642,7 +642,7 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     }
     const size_t cap = 160u * 1024u;
     // resident workgroups per CU: the launch bounds allow 24 (8-wave) / 16 (16-wave) waves, LDS the rest
-    const uint32_t per_cu = (uint32_t)std::min((size_t)(WAVES == 8 ? 3 : 1), cap / std::max(lds, (size_t)1));
+    const uint32_t per_cu = (uint32_t)std::min((size_t)(WAVES == 8 ? 3 : (WAVES == 12 ? 2 : 1)), cap / std::max(lds, (size_t)1));
     const uint32_t pixels = a.n_local_tiles * ((a.W + 7u) / 8u) * 64u;
     uint32_t blocks = 256u * (per_cu ? per_cu : 1u);
     // Frames in flight share the chip: each takes ONE workgroup per CU (256), whatever their number.  Four
@@ -680,6 +680,10 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     // leave room for one 16-wave workgroup only (C5: 128 KB of nodes) get six-entry lists: 2 KB per wave again.
     constexpr size_t per_wave = (size_t)CAP * 256u + 512u, per_wave6 = 6u * 256u + 512u;
     if (nodes + 8u * per_wave <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * per_wave, s);
+    // two 12-wave workgroups per CU keep six waves per SIMD for scenes between the two forms (~1100-1500 spheres:
+    // 1200 / 1400 / 1500 spheres at 4K 2.58 / 2.83 / 2.88 -> 2.32 / 2.55 / 2.59 ms per frame in flight; with six-entry
+    // lists the window would reach 1700 spheres for another 1-3 %: not worth four more instantiations)
+    if (nodes + 12u * per_wave <= cap / 2u) return launch_bvh_as<12, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 12u * per_wave, s);
     if (nodes + 16u * per_wave <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave, s);
     if (nodes + 16u * per_wave6 <= cap)    return launch_bvh_as<16, SGN, true, 6, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave6, s);
     return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * per_wave, s);

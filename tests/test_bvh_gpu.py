@@ -73,6 +73,18 @@ def test_large_scene_nodes_in_global_memory(oracle):
     assert st["rays"] == rays
 
 
+@pytest.mark.parametrize("n", [1150, 1450])
+def test_mid_size_scenes_take_the_twelve_wave_form(oracle, n):
+    """Between the scenes whose nodes leave room for three 8-wave workgroups per CU and those that need a whole CU's
+    LDS, two 12-wave workgroups run (rt_bvh.hip: launch_bvh)."""
+    scene = rt.SceneRaytracing().createScene(synthetic_spheres(n, 41))
+    W, H, B = 200, 120, 5
+    ref, _, rays = oracle_render(oracle, scene, W, H, B)
+    img, st = gpu_render(scene, W, H, B, strict=False, variant=BVH)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays
+
+
 def test_partitioned_ranks_reassemble(oracle):
     scene = rt.SceneRaytracing().createScene(synthetic_spheres(300, 5))
     W, H, B, world = 200, 123, 4, 3
