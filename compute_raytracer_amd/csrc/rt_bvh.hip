@@ -382,6 +382,12 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
 }
 
 // ---- kernel ---------------------------------------------------------------------------------------------
+// Do `k` workgroups with `bytes` of LDS each fit one CU?  The 160 KB are handed out in 128 granules of 1280 bytes and a
+// workgroup's allocation is rounded up to whole granules -- hipOccupancyMaxActiveBlocksPerMultiprocessor divides the
+// bytes and is one granule too generous: padding C3's 52,672-byte allocation, the third workgroup per CU stays up to
+// 53,760 bytes (42 granules) and is gone at 53,824 (1.855 -> 2.31 ms per frame; tools/knob_ab.py, profiles/r02/lds_cliff.log).
+// A scene just past such an edge must take the next form, not lose a third of its waves.
+inline bool lds_fits(size_t k, size_t bytes) { return k * ((bytes + 1279u) / 1280u) <= 128u; }
 // NLDS: node records and links staged in LDS (else read from global memory / L2: any scene size).
 // 8-wave workgroups are held to 80 VGPRs (6 waves per SIMD, three workgroups per CU): the walk is a
 // chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
@@ -640,9 +646,9 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const size_t cap = 160u * 1024u;
-    // resident workgroups per CU: the launch bounds allow 24 (8-wave) / 16 (16-wave) waves, LDS the rest
-    const uint32_t per_cu = (uint32_t)std::min((size_t)(WAVES == 8 ? 3 : (WAVES == 12 ? 2 : 1)), cap / std::max(lds, (size_t)1));
+    // resident workgroups per CU: the launch bounds allow 24 (8- and 12-wave) / 16 (16-wave) waves, LDS the rest
+    uint32_t per_cu = WAVES == 8 ? 3u : (WAVES == 12 ? 2u : 1u);
+    while (per_cu > 1u && !lds_fits(per_cu, lds)) --per_cu;
     const uint32_t pixels = a.n_local_tiles * ((a.W + 7u) / 8u) * 64u;
     uint32_t blocks = 256u * (per_cu ? per_cu : 1u);
     // Frames in flight share the chip: each takes ONE workgroup per CU (256), whatever their number.  Four
@@ -658,6 +664,10 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     if (blocks > need) blocks = need;
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_BLOCKS")) if (atoi(e) > 0) blocks = std::min((uint32_t)atoi(e), need);
+    if (const char* e = getenv("RT355_BVH_LDS_PAD")) {          // extra dynamic LDS: where does the third workgroup per CU go?
+        lds += (size_t)atoi(e);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
 #endif
     if (!a.sky_flat && !a.fin) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
@@ -679,11 +689,11 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     // per wave: CAP x 64 candidate entries + 64 eight-byte slots of running nearest hits.  Scenes whose nodes
     // leave room for one 16-wave workgroup only (C5: 128 KB of nodes) get six-entry lists: 2 KB per wave again.
     constexpr size_t per_wave = (size_t)CAP * 256u + 512u, per_wave6 = 6u * 256u + 512u;
-    if (nodes + 8u * per_wave <= cap / 3u) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * per_wave, s);
+    if (lds_fits(3u, nodes + 8u * per_wave)) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * per_wave, s);
     // two 12-wave workgroups per CU keep six waves per SIMD for scenes between the two forms (~1100-1500 spheres:
     // 1200 / 1400 / 1500 spheres at 4K 2.58 / 2.83 / 2.88 -> 2.32 / 2.55 / 2.59 ms per frame in flight; with six-entry
     // lists the window would reach 1700 spheres for another 1-3 %: not worth four more instantiations)
-    if (nodes + 12u * per_wave <= cap / 2u) return launch_bvh_as<12, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 12u * per_wave, s);
+    if (lds_fits(2u, nodes + 12u * per_wave)) return launch_bvh_as<12, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 12u * per_wave, s);
     if (nodes + 16u * per_wave <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave, s);
     if (nodes + 16u * per_wave6 <= cap)    return launch_bvh_as<16, SGN, true, 6, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave6, s);
     return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * per_wave, s);
