@@ -659,7 +659,10 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     // the next three start together when it ends, their tails then coincide for the rest of the batch
     // (2.50 ms); the host therefore asks for the share from the first frame on once it has seen frames
     // enqueued back to back (rt_api.hip: pipelined_hint).
-    if (a.grid_share > 1u) blocks = std::max(256u, blocks / a.grid_share);
+    // (the 12- and 16-wave forms, two and one workgroup per CU, do best with exactly their share -- 1300 spheres,
+    // 12-wave form, 96 / 128 / 160 / 256 workgroups per frame: 2.77 / 2.24 / 2.26 / 2.45 ms; 16-wave form 64 vs 256:
+    // 3.40 vs 3.48 ms at 2500 spheres, no difference at C5)
+    if (a.grid_share > 1u) blocks = WAVES == 8 ? std::max(256u, blocks / a.grid_share) : std::max(1u, blocks / a.grid_share);
     const uint32_t need = (pixels + 64u * WAVES - 1u) / (64u * WAVES);
     if (blocks > need) blocks = need;
 #ifdef RT_BVH_DEV_ENV
