@@ -6,12 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import compute_raytracer_amd as rt
 meta = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "frames.json")))["C3"]
 cfg = rt.BASELINE_CONFIGS["C3"]
-scene = rt.synthetic_scene(cfg["spheres"], cfg["seed"])
+spheres = int(os.environ.get("SOAK_SPHERES", cfg["spheres"]))       # other counts (other kernel forms): hashed against the first frame
+scene = rt.synthetic_scene(spheres, cfg["seed"])
 textured = len(sys.argv) > 2 and sys.argv[2] == "sky"
 r = rt.RendererRaytracing(cfg["width"], cfg["height"], scene, maxBounces=cfg["bounces"]).initialize(
     rt.CubemapMaterial.synthetic_daylight() if textured else None)
 r.recalculateScene()
-if textured:
+if textured or spheres != cfg["spheres"]:
     r.render()
     meta = {"sha256": hashlib.sha256(r.read_pixels().tobytes()).hexdigest(), "rays": r.stats()["rays"]}
 bad = 0; t0 = time.time(); frames = 0
