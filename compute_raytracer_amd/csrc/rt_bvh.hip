@@ -695,8 +695,9 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     if (lds_fits(3u, nodes + 8u * per_wave)) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * per_wave, s);
     // two 12-wave workgroups per CU keep six waves per SIMD for scenes between the two forms (~1100-1500 spheres:
     // 1200 / 1400 / 1500 spheres at 4K 2.58 / 2.83 / 2.88 -> 2.32 / 2.55 / 2.59 ms per frame in flight; with six-entry
-    // lists the window would reach 1700 spheres for another 1-3 %: not worth four more instantiations)
+    // lists the window reaches ~1750 spheres: 1600 / 1700 spheres 2.90 / 2.95 -> 2.65 / 2.71 ms)
     if (lds_fits(2u, nodes + 12u * per_wave)) return launch_bvh_as<12, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 12u * per_wave, s);
+    if (lds_fits(2u, nodes + 12u * per_wave6)) return launch_bvh_as<12, SGN, true, 6, RT_BVH_TAIL_SMALL>(a, nodes + 12u * per_wave6, s);
     if (nodes + 16u * per_wave <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave, s);
     if (nodes + 16u * per_wave6 <= cap)    return launch_bvh_as<16, SGN, true, 6, RT_BVH_TAIL_LARGE>(a, nodes + 16u * per_wave6, s);
     return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * per_wave, s);

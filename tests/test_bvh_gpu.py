@@ -73,7 +73,7 @@ def test_large_scene_nodes_in_global_memory(oracle):
     assert st["rays"] == rays
 
 
-@pytest.mark.parametrize("n", [1150, 1450])
+@pytest.mark.parametrize("n", [1150, 1450, 1650])
 def test_mid_size_scenes_take_the_twelve_wave_form(oracle, n):
     """Between the scenes whose nodes leave room for three 8-wave workgroups per CU and those that need a whole CU's
     LDS, two 12-wave workgroups run (rt_bvh.hip: launch_bvh)."""
