@@ -1,6 +1,6 @@
 """Development probe: C3's frame (3840x2160, 8 bounces) at other sphere counts through the hierarchy (variant 4) and the
 brute-force kernels (variant 5): one frame at a time (kernel ms, min of 8) and frames in flight (ms per frame).
-usage: python tools/count_sweep.py [counts, e.g. 96,160,256,512,768,1024]"""
+usage: [KNOB_WORLD=8] python tools/count_sweep.py [counts, e.g. 96,160,256,512,768,1024]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import compute_raytracer_amd as rt
@@ -10,7 +10,8 @@ for n in counts:
     scene = rt.synthetic_scene(n, cfg["seed"])
     row = []
     for v in (4, 5):
-        r = rt.RendererRaytracing(cfg["width"], cfg["height"], scene, maxBounces=cfg["bounces"]).initialize()
+        r = rt.RendererRaytracing(cfg["width"], cfg["height"], scene, maxBounces=cfg["bounces"], rank=0,
+                                  world=int(os.environ.get("KNOB_WORLD", "1"))).initialize()
         r.set_variant(v)
         ms = []
         for _ in range(10):
