@@ -139,7 +139,7 @@ def cpu_baseline_tri(cfg, scene, mat, sky, target_s, gpu_frame):
     return {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": "oracle/rt_oracle.c triangle path (scalar fp32 C, OpenMP over rows) on %d of %d 8-row tiles (every %d-th) "
-                  "of the same %dx%d / %d-triangle / %d-bounce frame: %d rays in %.1f s" % (n, ntiles, step, W, H, len(scene.triangles), B, rays, dt),
+                  "of the same %dx%d / %d-triangle / %d-bounce frame: %d rays in %.1f s" % (n, ntiles, step, W, H, scene.triangleCount, B, rays, dt),
         "fps_equiv": (n / ntiles) / dt,
         "gather_bytes_per_ray": (32.0 * nodes + 160.0 * tests + 80.0 * blas) / max(rays, 1),
         "per_ray": {"node_loads_32B": nodes / max(rays, 1), "triangle_tests_160B": tests / max(rays, 1), "instance_records_80B": blas / max(rays, 1)},
@@ -341,7 +341,7 @@ def main():
         local_rows = tiles.tiles_of_rank(H, 0, world) * 8
         hbm_bytes = 4 * W * min(local_rows, H) + 32 * N + 96
         if tri:     # image store + the scene read once: 160-B triangles, 32-B nodes, 80-B instance records, two f32 lookups
-            hbm_bytes = 4 * W * min(local_rows, H) + 164 * len(scene.triangles) + 32 * len(scene.nodes) + 84 * len(scene.models) + 96
+            hbm_bytes = 4 * W * min(local_rows, H) + 164 * scene.triangleCount + 32 * scene.node_buffer_length() + 84 * len(scene.instances) + 96
         hbm_gbps = hbm_bytes / (roof_ms * 1e-3) / 1e9
 
         # executed work of the dominant kernel, from the committed PMC summary (tools/pmc_summary.py)
@@ -413,7 +413,7 @@ def main():
                 roof.update({"achieved": None, "frac": None, "basis": "gather counts come from the cpu_baseline leg (--no-cpu-baseline given)"})
             check = {"sampled_tiles_match_oracle": cpu["gpu_rows_match"]} if cpu is not None else None
         out = {
-            "metric": ("Mrays/s at %dx%d, %d triangles, %d bounces" % (W, H, len(scene.triangles), B)) if tri else
+            "metric": ("Mrays/s at %dx%d, %d triangles, %d bounces" % (W, H, scene.triangleCount, B)) if tri else
                       ("Mrays/s at %dx%d, %d spheres, %d bounces" % (W, H, N, B)),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "frames_per_s": 1e3 / ms_per_step,
@@ -422,7 +422,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("%s: %dx%d, procedural triangle scene of the reference scene's size (%d triangles, %d instances, "
                                     "%d nodes; seed %d), %d bounces, constant sky, reference default camera/light"
-                                    % (name, W, H, len(scene.triangles), len(scene.models), len(scene.nodes), cfg["seed"], B)) if tri else
+                                    % (name, W, H, scene.triangleCount, len(scene.instances), scene.node_buffer_length(), cfg["seed"], B)) if tri else
                                    "%s: %dx%d, %d spheres (seed %d), %d bounces, %s, reference default camera/light"
                                    % (name, W, H, N, cfg["seed"], B, "6x512^2 procedural sky cube" if cfg["skybox"] else "constant sky"),
                        "mode": a.mode, "variant": a.variant, "rays_per_frame": rays_frame,

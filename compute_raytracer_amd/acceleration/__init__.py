@@ -1,7 +1,4 @@
-"""Mirror of src/rendering-raycast/acceleration/{aabb,blas,bvh,node}.ts."""
-from .node import Node
-from .aabb import AABB
-from .blas import BLAS
-from .bvh import BVH
+"""Bottom-level trees of the triangle path (the RESULT of src/rendering-raycast/acceleration/bvh.ts, as arrays)."""
+from .bvh import MeshTree, build_tree
 
-__all__ = ["Node", "AABB", "BLAS", "BVH"]
+__all__ = ["MeshTree", "build_tree"]

@@ -2,7 +2,7 @@
 mousey OBJ files and the mousey texture stay upstream), so tests and `bench.py --config TRI` build
 scenes of the same SHAPE from generated OBJ text: tessellated spheres instanced as models plus a
 floor quad, through the same loader, SAH builder and top-level builder as a real asset would take
-(obj_reader.py, acceleration/bvh.py, scene_raytracing.py)."""
+(soup.py, acceleration/bvh.py, instances.py, scene_raytracing.py)."""
 import math
 
 import numpy as np
@@ -43,21 +43,21 @@ def obj_floor(half=1.0):
 def triangle_scene(seed=1, n_models=3, rings=6, sectors=8, spin=True):
     """Meshes: two UV spheres of different tessellation + a floor; models: instances of them,
     translated and rotated about Y, laid out in front of the reference's default camera."""
-    from . import Material, Mesh, Model, SceneRaytracing
+    from . import Material, SceneRaytracing, load_mesh
     rng = np.random.default_rng(seed)
     meshes = [
-        Mesh().initializeFromText(obj_uv_sphere(rings, sectors, 1.0), dict(color=[0.9, 0.5, 0.3, 0.6], alignBottom=True, scale=1.0)),
-        Mesh().initializeFromText(obj_uv_sphere(rings + 2, sectors + 3, 1.0, quads=False), dict(color=[0.3, 0.7, 0.9, 1.0], alignBottom=True, scale=0.7)),
-        Mesh().initializeFromText(obj_floor(1.0), dict(color=[1.0, 1.0, 1.0, 0.8], alignBottom=False, scale=12)),
+        load_mesh(obj_uv_sphere(rings, sectors, 1.0), dict(color=[0.9, 0.5, 0.3, 0.6], alignBottom=True, scale=1.0)),
+        load_mesh(obj_uv_sphere(rings + 2, sectors + 3, 1.0, quads=False), dict(color=[0.3, 0.7, 0.9, 1.0], alignBottom=True, scale=0.7)),
+        load_mesh(obj_floor(1.0), dict(color=[1.0, 1.0, 1.0, 0.8], alignBottom=False, scale=12)),
     ]
     models = []
     for i in range(n_models):
         pos = [float(rng.uniform(-4, 4)), 0.0, float(rng.uniform(-9, -3))]
-        m = Model(i % 2, pos, [0, float(rng.uniform(0, 360)), 0])
+        m = dict(meshIndex=i % 2, position=pos, eulers=[0, float(rng.uniform(0, 360)), 0])
         if spin:
-            m.eulerSpeed = [0, float(rng.uniform(-90, 90)), 0]
+            m["eulerSpeed"] = [0, float(rng.uniform(-90, 90)), 0]
         models.append(m)
-    models.append(Model(2, [0, 0, -5], [0, 0, 0]))
+    models.append(dict(meshIndex=2, position=[0, 0, -5], eulers=[0, 0, 0]))
     scene = SceneRaytracing().createScene([])
     scene.createTriangleScene(meshes, models)
     tex = rng.integers(0, 256, (16, 24, 4), dtype=np.uint8)

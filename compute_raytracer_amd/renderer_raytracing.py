@@ -72,7 +72,7 @@ class RendererRaytracing:
         p = self.scene.pack_params(self.maxBounces)                              # RR:157-165
         abi.check(L.rt_write_params(c, p.ctypes.data_as(ctypes.POINTER(ctypes.c_float))), c)
         fp = ctypes.POINTER(ctypes.c_float)
-        if self.scene.triangles:                                                 # the reference's live scene type
+        if self.scene.hasTriangles:                                                 # the reference's live scene type
             b = np.ascontiguousarray(self.scene.pack_blas(), dtype=np.float32)           # RR:169-174
             abi.check(L.rt_write_blas(c, b.ctypes.data_as(fp), b.shape[0]), c)
             bl = np.ascontiguousarray(self.scene.pack_blas_lookup(), dtype=np.float32)   # RR:177-181
@@ -82,7 +82,7 @@ class RendererRaytracing:
         if self.loaded:                                                          # RR:194-195
             return
         self.loaded = True
-        if self.scene.triangles:
+        if self.scene.hasTriangles:
             t = np.ascontiguousarray(self.scene.pack_triangles(), dtype=np.float32)      # RR:198-209
             abi.check(L.rt_write_triangles(c, t.ctypes.data_as(fp), t.shape[0]), c)
             nb = np.ascontiguousarray(self.scene.pack_blas_nodes(), dtype=np.float32)    # RR:212-223

@@ -69,28 +69,52 @@ def synthetic_spheres(n, seed):
     return spheres
 
 
+class TriMesh:
+    """One mesh of a triangle scene: its soup and its bottom-level tree (what mesh.ts:16-21 loads),
+    plus where the scene put them (scene-raytracing.ts:75-79, 116-120)."""
+    __slots__ = ("soup", "tree", "lookup_offset", "root_node")
+
+    def __init__(self, soup, tree=None):
+        from .acceleration.bvh import build_tree
+        self.soup = soup
+        self.tree = tree if tree is not None else build_tree(soup)
+        self.lookup_offset = 0
+        self.root_node = 0
+
+
+def load_mesh(obj_text, descriptor):
+    from .soup import parse_obj
+    return TriMesh(parse_obj(obj_text, descriptor))
+
+
+def load_mesh_file(path, descriptor):
+    with open(path, "r", newline="") as f:               # keep '\r': the loader splits on '\n' only
+        return load_mesh(f.read(), descriptor)
+
+
 class SceneRaytracing:
-    """Public fields as in scene-raytracing.ts:13-35: `camera`, `light`, `spheres` for sphere
-    scenes; `triangles`, `triangleIndices`, `nodes`, `blasList`, `blasIndices`, `tlasNodesMax`,
-    `tlasNodesUsed`, `blasNodesUsed`, `meshes`, `models` for the reference's live triangle scene
-    (createTriangleScene / createReferenceScene)."""
+    """`camera`, `light`, `spheres` for sphere scenes (scene-raytracing.ts:13-18).  A triangle scene --
+    the reference's live scene type, scene-raytracing.ts:47-272 -- is held as the upload buffers
+    themselves: `static` = {triangles (T,40), blas_nodes (B,8), tri_lookup (T,)} packed once,
+    `frame` = {blas (M,20), blas_lookup (M,), tlas_nodes (U,8)} rebuilt by update(dt); `meshes` are
+    TriMesh (soup + tree arrays), `instances` an Instances array set (instances.py)."""
 
     def __init__(self):
         self.camera = None
         self.light = None
         self.spheres = []
-        # triangle-scene members (scene-raytracing.ts:19-35); empty for sphere scenes
         self.meshes = []
-        self.models = []
-        self.triangles = []
-        self.triangleIndices = []
-        self.nodes = []
-        self.blasList = []
-        self.blasIndices = []
+        self.instances = None
+        self.static = None
+        self.frame = None
+        self.triangleCount = 0
         self.tlasNodesMax = 0
         self.tlasNodesUsed = 0
         self.blasNodesUsed = 0
-        self.blasConsumed = False
+
+    @property
+    def hasTriangles(self):
+        return self.triangleCount > 0
 
     def createScene(self, spheres=None):  # scene-raytracing.ts:37-45
         self.camera = Camera([0.0593, 2.692, 3.293], 106, 270)
@@ -99,193 +123,81 @@ class SceneRaytracing:
         return self
 
     def update(self, dt):  # scene-raytracing.ts:138-143
-        """Spheres are static; a triangle scene advances its models and rebuilds the TLAS and
-        every BLAS (boxes + inverse matrices), as the reference does each frame."""
-        if self.models:
-            for model in self.models:
-                model.update(dt)
-            self.buildBVH()
+        """Spheres are static; a triangle scene turns its instances and rebuilds the per-frame buffers
+        (instance matrices, their inverses, the top-level tree), as the reference does each frame."""
+        if self.instances is not None and len(self.instances):
+            self.instances.turn(dt)
+            self.buildTopLevel()
 
-    # ---- the reference's live scene type: meshes + models + two-level BVH (SR:47-272) --------
-    def createTriangleScene(self, meshes, models):
-        """scene-raytracing.ts:37-136 with the mesh list and the model list supplied by the
-        caller (the reference hard-codes cat / mousey / flat, see createReferenceScene)."""
+    # ---- the reference's live scene type: meshes + instances + two-level tree (SR:47-272) --------
+    def createTriangleScene(self, meshes, instances):
+        """meshes: TriMesh list; instances: Instances (or the records Instances.from_records takes)."""
+        from .instances import Instances
         if self.camera is None:
             self.createScene([])
         self.meshes = list(meshes)
-        self.triangles = []                                    # SR:75-79
-        for mesh in self.meshes:
-            mesh.triangleLookupOffset = len(self.triangles)
-            self.triangles.extend(mesh.triangles)
-        self.triangleIndices = [0] * len(self.triangles)       # SR:82-93
-        i = offset = 0
-        for mesh in self.meshes:
-            for j in range(len(mesh.bvh.triangleIndices)):
-                self.triangleIndices[i] = mesh.bvh.triangleIndices[j] + offset
-                i += 1
-            offset += len(mesh.bvh.triangleIndices)
-        self.models = list(models)                             # SR:96-111
-        self.tlasNodesMax = 2 * len(self.models) - 1           # SR:114
-        self.blasNodesUsed = 0                                 # SR:116-120
-        for mesh in self.meshes:
-            mesh.rootNodeIndex = self.tlasNodesMax + self.blasNodesUsed
-            self.blasNodesUsed += mesh.bvh.nodesUsed
-        from .acceleration.node import Node
-        self.nodes = [None] * (self.tlasNodesMax + self.blasNodesUsed)   # SR:123-131
-        for i in range(self.tlasNodesMax):
-            node = Node()
-            node.leftChildIndex = 0
-            node.primitiveCount = 0
-            node.minCorner = [0, 0, 0]
-            node.maxCorner = [0, 0, 0]
-            self.nodes[i] = node
-        self.buildBVH()                                        # SR:133
-        self.finalizeBVH()                                     # SR:134
-        self.blasConsumed = True
+        self.instances = instances if isinstance(instances, Instances) else Instances.from_records(instances)
+        at = 0
+        for mesh in self.meshes:                               # SR:75-79
+            mesh.lookup_offset = at
+            at += mesh.soup.count
+        self.triangleCount = at
+        self.tlasNodesMax = 2 * len(self.instances) - 1        # SR:114
+        nodes = 0
+        for mesh in self.meshes:                               # SR:116-120
+            mesh.root_node = self.tlasNodesMax + nodes
+            nodes += mesh.tree.used
+        self.blasNodesUsed = nodes
+        z40, z8 = np.zeros((0, 40), np.float32), np.zeros((0, 8), np.float32)
+        self.static = dict(
+            triangles=np.concatenate([m.soup.pack() for m in self.meshes] + [z40]),                       # RR:198-209
+            blas_nodes=np.concatenate([m.tree.nodes(m.root_node, m.lookup_offset) for m in self.meshes] + [z8]),   # RR:212-223, SR:256-272
+            tri_lookup=np.concatenate([(m.tree.order + m.lookup_offset).astype(np.float64) for m in self.meshes]
+                                      + [np.zeros(0)]).astype(np.float32))                                # RR:225-229, SR:82-93
+        self.buildTopLevel()
         return self
 
-    def createReferenceScene(self, models_dir):
+    def createReferenceScene(self, models_dir, mousey_xz=(2.5, 0.0), cat_xz=(-2.5, 0.0), mousey_yaw=45.0):
         """The reference's own scene (SR:47-111): cat, mousey and a flat floor, from the OBJ files
-        under src/assets/models (not shipped with this repository)."""
+        under src/assets/models (they do not travel with this repository).  The keyword arguments are
+        the dat.GUI state of src/app.ts:97-113 (positions) and the spin angle reached (SR:104)."""
         import os
-        from .mesh import Mesh
-        from .model.model import Model
         self.createScene([])
-        mousey = Mesh().initialize(os.path.join(models_dir, "mousey", "mousey.obj"),
-                                   dict(color=[1.0, 1.0, 1.0, 0.3], alignBottom=True, invertYZ=False, scale=0.025))
-        cat = Mesh().initialize(os.path.join(models_dir, "cat.obj"),
-                                dict(color=[0.8, 0.6, 0.7, 1.0], alignBottom=True, invertYZ=False, scale=0.1))
-        flat = Mesh().initialize(os.path.join(models_dir, "flat.obj"),
-                                 dict(color=[1.0, 1.0, 1.0, 1.0], alignBottom=False, invertYZ=False, scale=10))
-        meshes = [cat, mousey, flat]                           # SR:71
-        models = [Model(x, [5 * x - 2.5, 0, 0], [180, 45 * x, 0]) for x in range(2)]   # SR:97-102
-        models[1].eulerSpeed = [0, 45, 0]                      # SR:104
-        models.append(Model(meshes.index(flat), [0, 0, 0], [0, 0, 0]))                 # SR:107-111
-        return self.createTriangleScene(meshes, models)
+        mousey = load_mesh_file(os.path.join(models_dir, "mousey", "mousey.obj"),
+                                dict(color=[1.0, 1.0, 1.0, 0.3], alignBottom=True, invertYZ=False, scale=0.025))
+        cat = load_mesh_file(os.path.join(models_dir, "cat.obj"),
+                             dict(color=[0.8, 0.6, 0.7, 1.0], alignBottom=True, invertYZ=False, scale=0.1))
+        flat = load_mesh_file(os.path.join(models_dir, "flat.obj"),
+                              dict(color=[1.0, 1.0, 1.0, 1.0], alignBottom=False, invertYZ=False, scale=10))
+        records = [dict(meshIndex=0, position=[cat_xz[0], 0, cat_xz[1]], eulers=[180, 0, 0]),              # SR:97-102
+                   dict(meshIndex=1, position=[mousey_xz[0], 0, mousey_xz[1]], eulers=[180, mousey_yaw, 0], eulerSpeed=[0, 45, 0]),   # SR:104
+                   dict(meshIndex=2, position=[0, 0, 0], eulers=[0, 0, 0])]                                # SR:107-111
+        return self.createTriangleScene([cat, mousey, flat], records)                                      # SR:71
 
-    def buildBVH(self):                                        # SR:145-179
-        from .acceleration.blas import BLAS
-        self.tlasNodesUsed = 0
-        n = len(self.models)
-        self.blasList = [None] * n
-        self.blasIndices = [0] * n
-        for i in range(self.tlasNodesMax):
-            nd = self.nodes[i]
-            nd.leftChildIndex = 0
-            nd.primitiveCount = 0
-            nd.minCorner = [0, 0, 0]
-            nd.maxCorner = [0, 0, 0]
-        for i, model in enumerate(self.models):
-            mesh = self.meshes[model.meshIndex]
-            # quirk kept: mesh.bvh.minCorner/maxCorner are the constructor's +-999999 placeholders
-            # (bvh.ts:23-25 sets them, nothing updates them), so every BLAS box is huge
-            self.blasList[i] = BLAS(mesh.rootNodeIndex, mesh.bvh.minCorner, mesh.bvh.maxCorner, model.model)
-            self.blasIndices[i] = i
-        root = self.nodes[0]
-        root.leftChildIndex = 0
-        root.primitiveCount = len(self.blasList)
-        self.tlasNodesUsed += 1
-        self._updateBounds(0)
-        self._subdivide(0)
+    def buildTopLevel(self):                                   # SR:145-254 into the buffers of RR:169-192
+        from .instances import invert_mat4, top_level, world_boxes
+        inst = self.instances
+        mats = inst.matrices()
+        blas = np.zeros((len(inst), 20), dtype=np.float32)
+        blas[:, 0:16] = invert_mat4(mats)
+        blas[:, 16] = [self.meshes[k].root_node for k in inst.mesh_index]
+        box_lo = np.array([self.meshes[k].tree.box_lo for k in inst.mesh_index]).reshape(-1, 3)
+        box_hi = np.array([self.meshes[k].tree.box_hi for k in inst.mesh_index]).reshape(-1, 3)
+        lo, hi, centre = world_boxes(mats, box_lo, box_hi)
+        nodes, lookup = top_level(lo, hi, centre)
+        self.tlasNodesUsed = nodes.shape[0]
+        self.frame = dict(blas=blas, blas_lookup=lookup, tlas_nodes=nodes)
 
-    def _updateBounds(self, nodeIndex):                        # SR:181-191
-        node = self.nodes[nodeIndex]
-        node.minCorner = [1e30, 1e30, 1e30]
-        node.maxCorner = [-1e30, -1e30, -1e30]
-        for i in range(node.primitiveCount):
-            blas = self.blasList[self.blasIndices[node.leftChildIndex + i]]
-            for k in range(3):
-                node.minCorner[k] = min(node.minCorner[k], float(blas.minCorner[k]))
-                node.maxCorner[k] = max(node.maxCorner[k], float(blas.maxCorner[k]))
-
-    def _subdivide(self, nodeIndex):                           # SR:193-254
-        from . import glmatrix as glm
-        node = self.nodes[nodeIndex]
-        if node.primitiveCount < 2:
-            return
-        extent = glm.vec3_subtract(glm.vec3_create(), node.maxCorner, node.minCorner)
-        axis = 0
-        if float(extent[1]) > float(extent[axis]): axis = 1
-        if float(extent[2]) > float(extent[axis]): axis = 2
-        splitPosition = node.minCorner[axis] + float(extent[axis]) / 2
-        i = node.leftChildIndex
-        j = i + node.primitiveCount - 1
-        while i <= j:
-            if float(self.blasList[self.blasIndices[i]].center[axis]) < splitPosition:
-                i += 1
-            else:
-                self.blasIndices[i], self.blasIndices[j] = self.blasIndices[j], self.blasIndices[i]
-                j -= 1
-        leftCount = i - node.leftChildIndex
-        if leftCount == 0 or leftCount == node.primitiveCount:
-            return
-        leftChildIndex = self.tlasNodesUsed
-        self.tlasNodesUsed += 1
-        rightChildIndex = self.tlasNodesUsed
-        self.tlasNodesUsed += 1
-        self.nodes[leftChildIndex].leftChildIndex = node.leftChildIndex
-        self.nodes[leftChildIndex].primitiveCount = leftCount
-        self.nodes[rightChildIndex].leftChildIndex = i
-        self.nodes[rightChildIndex].primitiveCount = node.primitiveCount - leftCount
-        node.leftChildIndex = leftChildIndex
-        node.primitiveCount = 0
-        self._updateBounds(leftChildIndex)
-        self._updateBounds(rightChildIndex)
-        self._subdivide(leftChildIndex)
-        self._subdivide(rightChildIndex)
-
-    def finalizeBVH(self):                                     # SR:256-272
-        for mesh in self.meshes:
-            for i in range(mesh.bvh.nodesUsed):
-                meshNode = mesh.bvh.nodes[i]
-                if meshNode.primitiveCount == 0:
-                    meshNode.leftChildIndex += mesh.rootNodeIndex
-                else:
-                    meshNode.leftChildIndex += mesh.triangleLookupOffset
-                self.nodes[mesh.rootNodeIndex + i] = meshNode
-
-    # ---- packing of the triangle scene, as RR:169-229 ----
-    def pack_blas(self):                                       # RR:169-174
-        a = np.zeros((len(self.blasList), 20), dtype=np.float32)
-        for i, b in enumerate(self.blasList):
-            a[i, 0:16] = b.inverseModel
-            a[i, 16] = np.float32(b.rootNodeIndex)
-        return a
-
-    def pack_blas_lookup(self):                                # RR:177-181 (indices as f32)
-        return np.asarray(self.blasIndices, dtype=np.float64).astype(np.float32)
-
-    def pack_tlas_nodes(self):                                 # RR:184-192
-        return self._pack_nodes(0, self.tlasNodesUsed)
-
-    def pack_blas_nodes(self):                                 # RR:212-223 (written at byte 32*tlasNodesMax)
-        return self._pack_nodes(self.tlasNodesMax, self.blasNodesUsed)
-
-    def _pack_nodes(self, first, count):
-        a = np.zeros((count, 8), dtype=np.float32)
-        for i in range(count):
-            nd = self.nodes[first + i]
-            a[i, 0:3] = np.asarray(nd.minCorner, dtype=np.float64).astype(np.float32)
-            a[i, 3] = np.float32(nd.leftChildIndex)
-            a[i, 4:7] = np.asarray(nd.maxCorner, dtype=np.float64).astype(np.float32)
-            a[i, 7] = np.float32(nd.primitiveCount)
-        return a
-
-    def pack_triangles(self):                                  # RR:198-209
-        a = np.zeros((len(self.triangles), 40), dtype=np.float32)
-        for i, t in enumerate(self.triangles):
-            for corner in range(3):
-                a[i, 12 * corner:12 * corner + 3] = np.asarray(t.corners[corner], dtype=np.float64).astype(np.float32)
-                a[i, 12 * corner + 4:12 * corner + 7] = np.asarray(t.normals[corner], dtype=np.float64).astype(np.float32)
-                a[i, 12 * corner + 8:12 * corner + 10] = np.asarray(t.textures[corner], dtype=np.float64).astype(np.float32)
-            a[i, 36:40] = np.asarray(t.color, dtype=np.float64).astype(np.float32)
-        return a
-
-    def pack_tri_lookup(self):                                 # RR:225-229
-        return np.asarray(self.triangleIndices, dtype=np.float64).astype(np.float32)
+    # ---- the upload buffers by the names RendererRaytracing asks for (RR:169-229) ----
+    def pack_blas(self): return self.frame["blas"]
+    def pack_blas_lookup(self): return self.frame["blas_lookup"]
+    def pack_tlas_nodes(self): return self.frame["tlas_nodes"]
+    def pack_blas_nodes(self): return self.static["blas_nodes"]
+    def pack_triangles(self): return self.static["triangles"]
+    def pack_tri_lookup(self): return self.static["tri_lookup"]
 
     def node_buffer_length(self):                              # RR:149-152: 32 * nodes.length bytes
-        return len(self.nodes)
+        return self.tlasNodesMax + self.blasNodesUsed
 
     # ---- packing, as RendererRaytracing.recalculateScene does it (RR:157-165) ----
     def pack_params(self, maxBounces):

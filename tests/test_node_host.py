@@ -176,10 +176,9 @@ def _obj_spec():
 
 
 def _python_scene(meshes, models, updates):
-    pm = [rt.Mesh().initializeFromText(m["obj"], m["descriptor"]) for m in meshes]
-    pmod = [rt.Model(m["meshIndex"], m["position"], m["eulers"], m.get("eulerSpeed")) for m in models]
+    pm = [rt.load_mesh(m["obj"], m["descriptor"]) for m in meshes]
     scene = rt.SceneRaytracing().createScene([])
-    scene.createTriangleScene(pm, pmod)
+    scene.createTriangleScene(pm, models)
     for dt in updates:
         scene.update(dt)
     return scene
@@ -190,7 +189,7 @@ def _bits(a):
 
 
 def _compare_js_with_python(js, scene):
-    assert js["nTriangles"] == len(scene.triangles) and js["tlasNodesUsed"] == scene.tlasNodesUsed
+    assert js["nTriangles"] == scene.triangleCount and js["tlasNodesUsed"] == scene.tlasNodesUsed
     assert js["tlasNodesMax"] == scene.tlasNodesMax and js["blasNodesUsed"] == scene.blasNodesUsed
     assert js["blas"] == _bits(scene.pack_blas())
     assert js["blasIndices"] == _bits(scene.pack_blas_lookup())
@@ -198,13 +197,12 @@ def _compare_js_with_python(js, scene):
     assert js["blasNodes"] == _bits(scene.pack_blas_nodes())
     assert js["triangleIndices"] == _bits(scene.pack_tri_lookup())
     assert js["triangles"] == _bits(scene.pack_triangles())
-    cen = np.array([np.asarray(t.centroid, dtype=np.float32) for t in scene.meshes[0].triangles])
-    assert js["centroids0"] == _bits(cen)
+    assert js["centroids0"] == _bits(scene.meshes[0].soup.centroid)
 
 
 def test_js_scene_builders_match_python_mirror(tmp_path):
     """OBJ text -> triangle soup -> SAH tree -> instance matrices -> top-level tree, built twice: by the
-    data-oriented node/*.js (typed arrays, explicit stacks) and by the object-style Python mirror.  Every
+    data-oriented node/*.js (typed arrays, scalar loops, explicit stacks) and by the numpy host (whole-array arithmetic).  Every
     f32 of every upload buffer must agree bit for bit (two independent restatements of what
     scene-raytracing.ts, bvh.ts, blas.ts, model.ts, obj-reader.ts and gl-matrix compute)."""
     meshes, models = _obj_spec()

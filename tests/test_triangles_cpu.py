@@ -10,14 +10,15 @@ import pytest
 
 import compute_raytracer_amd as rt
 from compute_raytracer_amd import glmatrix as glm
-from compute_raytracer_amd.model.reader.obj_reader import ObjectReader, _parse_float
+from compute_raytracer_amd.instances import Instances, invert_mat4, top_level, world_boxes
+from compute_raytracer_amd.soup import js_parse_float, parse_obj
 from helpers import obj_floor, obj_uv_sphere, tri_buffers, triangle_scene
 
 F = np.float32
 REF_MODELS = "/root/reference/src/assets/models"
 
 
-# ---- gl-matrix restatement ---------------------------------------------------------------------------
+# ---- gl-matrix restatement (scalar form, kept as the yardstick of the array forms in instances.py) -----------
 def test_mat4_translate_rotate_invert():
     m = glm.mat4_create()
     glm.mat4_translate(m, m, [2.5, 0, -1])
@@ -38,89 +39,149 @@ def test_f32_stores_versus_plain_arrays():
     assert out32.dtype == F and out64 == [1.1, 1.2, 1.3] and float(out32[0]) != 1.1
 
 
-# ---- OBJ reader ----------------------------------------------------------------------------------------
+def test_instance_arrays_equal_scalar_glmatrix():
+    """instances.py forms every instance's matrix, inverse, world box and centre at once; the scalar
+    gl-matrix restatement, one call per stored value, must give the same bits."""
+    rng = np.random.default_rng(7)
+    m = 9
+    inst = Instances(np.zeros(m, int), rng.uniform(-8, 8, (m, 3)), rng.uniform(-400, 400, (m, 3)), rng.uniform(-90, 90, (m, 3)))
+    inst.turn(0.37); inst.turn(1.9)
+    assert np.all(np.abs(inst.eulers) <= 720)
+    mats = inst.matrices()
+    inv = invert_mat4(mats)
+    box_lo = np.tile([999999.0] * 3, (m, 1)); box_hi = -box_lo
+    lo, hi, centre = world_boxes(mats, box_lo, box_hi)
+    for k in range(m):
+        ref = glm.mat4_create()
+        glm.mat4_translate(ref, ref, inst.position[k])
+        glm.mat4_rotate_y(ref, ref, inst.eulers[k, 1] * math.pi / 180)
+        assert np.array_equal(ref.view(np.uint32), mats[k].view(np.uint32))
+        assert np.array_equal(glm.mat4_invert(glm.mat4_create(), ref).view(np.uint32), inv[k].view(np.uint32))
+        mn, mx, corner = [1e30] * 3, [-1e30] * 3, glm.vec3_create()
+        for c in range(8):
+            pt = [(-999999.0 if c & 4 else 999999.0), (-999999.0 if c & 2 else 999999.0), (-999999.0 if c & 1 else 999999.0)]
+            glm.vec3_transform_mat4(corner, pt, ref)
+            glm.vec3_min(mn, mn, corner); glm.vec3_max(mx, mx, corner)
+        assert mn == list(lo[k]) and mx == list(hi[k])
+        cen = glm.vec3_div(glm.vec3_create(), glm.vec3_add(glm.vec3_create(), mn, mx), [2, 2, 2])
+        assert np.array_equal(cen.view(np.uint32), centre[k].view(np.uint32))
+    assert np.array_equal(invert_mat4(np.zeros((1, 16), F))[0], glm.mat4_create())      # singular: identity stays
+
+
+# ---- OBJ text -> soup ----------------------------------------------------------------------------------
 def test_parse_float_is_js_parse_float():
-    assert _parse_float("+1.0") == 1.0 and _parse_float("-2.5e1x") == -25.0 and _parse_float("3\r") == 3.0
-    assert math.isnan(_parse_float("abc")) and math.isnan(_parse_float(""))
+    assert js_parse_float("+1.0") == 1.0 and js_parse_float("-2.5e1x") == -25.0 and js_parse_float("3\r") == 3.0
+    assert js_parse_float(".5") == 0.5 and js_parse_float("7.") == 7.0 and js_parse_float("-Infinity") == -math.inf
+    assert math.isnan(js_parse_float("abc")) and math.isnan(js_parse_float("")) and math.isnan(js_parse_float(None))
 
 
-def test_obj_reader_fan_triangulation_centering_and_scale():
-    tris = ObjectReader.loadMeshFromObjText(obj_floor(1.0), dict(color=[1, 1, 1, 1], scale=10))
-    assert len(tris) == 2                                   # quad -> fan of 2 (obj-reader.ts:103-117)
-    pts = np.array([c for t in tris for c in t.corners])
+def test_soup_fan_triangulation_centering_and_scale():
+    s = parse_obj(obj_floor(1.0), dict(color=[1, 1, 1, 1], scale=10))
+    assert s.count == 2                                     # quad -> fan of 2 (obj-reader.ts:103-117)
+    pts = s.position.reshape(-1, 3)
     assert pts.min() == -10 and pts.max() == 10 and np.all(pts[:, 1] == 0)
-    assert tris[0].corners[0] is tris[1].corners[0]         # both fans start at vertex 1
-    assert np.allclose(tris[0].centroid, np.mean(np.array(tris[0].corners), axis=0), atol=1e-6)
-    assert tris[0].centroid.dtype == F                      # vec3.create() -> Float32Array
-    sph = ObjectReader.loadMeshFromObjText(obj_uv_sphere(4, 6, 2.0, centre=(5, 5, 5)), dict(color=[1, 0, 0, 1], alignBottom=True, scale=0.5))
-    assert len(sph) == 4 * 6 * 2
-    pts = np.array([c for t in sph for c in t.corners])
+    assert np.array_equal(s.position[0, 0], s.position[1, 0])         # both fans start at vertex 1
+    assert np.allclose(s.centroid[0], s.position[0].mean(axis=0), atol=1e-6) and s.centroid.dtype == F
+    sph = parse_obj(obj_uv_sphere(4, 6, 2.0, centre=(5, 5, 5)), dict(color=[1, 0, 0, 1], alignBottom=True, scale=0.5))
+    assert sph.count == 4 * 6 * 2
+    pts = sph.position.reshape(-1, 3)
     assert abs(pts[:, 1].min()) < 1e-6 and abs(pts[:, 1].max() - 2.0) < 1e-6      # bottom aligned, scaled
     assert abs(pts[:, 0].min() + 1.0) < 1e-6 and abs(pts[:, 0].max() - 1.0) < 1e-6
+    rec = sph.pack()
+    assert rec.shape == (sph.count, 40) and rec.dtype == F
+    assert np.array_equal(rec[:, 12:15], sph.position[:, 1].astype(F)) and np.array_equal(rec[:, 28:31], sph.normal[:, 2].astype(F))
+    assert np.array_equal(rec[:, 8:10], sph.uv[:, 0].astype(F)) and np.all(rec[:, 36:40] == [1, 0, 0, 1])
+    assert np.all(rec[:, [3, 7, 10, 11]] == 0)
 
 
-def test_obj_reader_invert_yz_swaps_axes_and_winding():
-    a = ObjectReader.loadMeshFromObjText(obj_uv_sphere(3, 4), dict(color=[1, 1, 1, 1]))
-    b = ObjectReader.loadMeshFromObjText(obj_uv_sphere(3, 4), dict(color=[1, 1, 1, 1], invertYZ=True))
-    assert np.allclose(np.array(a[0].corners[0])[[0, 2, 1]], b[0].corners[0])
-    # face corners 2 and 3 are swapped as well (yIndex/zIndex index the FACE fields too)
-    assert np.allclose(np.array(a[0].corners[1])[[0, 2, 1]], b[0].corners[2])
-    ObjectReader.loadMeshFromObjText(obj_floor(), dict(color=[1, 1, 1, 1]))        # leave the static state un-swizzled
+def test_soup_invert_yz_swaps_axes_and_winding():
+    a = parse_obj(obj_uv_sphere(3, 4), dict(color=[1, 1, 1, 1]))
+    b = parse_obj(obj_uv_sphere(3, 4), dict(color=[1, 1, 1, 1], invertYZ=True))
+    assert np.allclose(a.position[0, 0][[0, 2, 1]], b.position[0, 0])
+    # face corners 2 and 3 are swapped as well (the swizzle indexes the FACE fields too)
+    assert np.allclose(a.position[0, 1][[0, 2, 1]], b.position[0, 2])
+
+
+def test_soup_loader_quirks():
+    # '\r' line ends, a doubled blank (an empty field = NaN), a face that names a vertex not read yet
+    s = parse_obj("v 0 0 0\r\nv 1 0 0\r\nv 0 1 0\r\nvt 0 0\r\nvn 0 0 1\r\nf 1/1/1 2/1/1 3/1/1\r\n", dict(color=[1, 1, 1, 1]))
+    assert s.count == 1 and np.array_equal(s.position[0, 1], [0.5, -0.5, 0])
+    s = parse_obj("v 0  0 0\nv 1 1 1\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 2/1/1\n", dict(color=[1, 1, 1, 1]))
+    assert np.isnan(s.position[0, 0, 1])
+    with pytest.raises(ValueError):
+        parse_obj("v 0 0 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\nv 1 0 0\nv 0 1 0\n", dict(color=[1, 1, 1, 1]))
+    # maxima are f32 as found, minima f64: the shift of a cloud [0, 0.1] is f32(f32(0 + f32(0.1)) / 2)
+    s = parse_obj("v 0 0 0\nv 0.1 0 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 2/1/1\n", dict(color=[1, 1, 1, 1]))
+    assert s.position[0, 0, 0] == -float(F(float(F(0.1)) / 2))
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="reference assets not present")
 def test_reference_scene_triangle_count():
     """The reference's own scene: 428 + 12,174 + 2 = 12,604 triangles, the 'Primitive count' of
-    info/sample_settings.png -- the one number of the reference that pins the OBJ reader."""
-    cat = rt.Mesh(); cat.triangles = ObjectReader.loadMeshFromObjFile(os.path.join(REF_MODELS, "cat.obj"), dict(color=[.8, .6, .7, 1], alignBottom=True, scale=0.1))
-    flat = rt.Mesh(); flat.triangles = ObjectReader.loadMeshFromObjFile(os.path.join(REF_MODELS, "flat.obj"), dict(color=[1, 1, 1, 1], scale=10))
-    mousey = ObjectReader.loadMeshFromObjFile(os.path.join(REF_MODELS, "mousey", "mousey.obj"), dict(color=[1, 1, 1, .3], alignBottom=True, scale=0.025))
-    assert (len(cat.triangles), len(mousey), len(flat.triangles)) == (428, 12174, 2)
+    info/sample_settings.png -- the one number of the reference that pins the OBJ loader."""
+    counts = [parse_obj(open(os.path.join(REF_MODELS, f), newline="").read(), d).count for f, d in
+              (("cat.obj", dict(color=[.8, .6, .7, 1], alignBottom=True, scale=0.1)),
+               (os.path.join("mousey", "mousey.obj"), dict(color=[1, 1, 1, .3], alignBottom=True, scale=0.025)),
+               ("flat.obj", dict(color=[1, 1, 1, 1], scale=10)))]
+    assert counts == [428, 12174, 2]
 
 
-# ---- BVH / TLAS builders ---------------------------------------------------------------------------------
-def test_sah_bvh_invariants():
-    tris = ObjectReader.loadMeshFromObjText(obj_uv_sphere(8, 12), dict(color=[1, 1, 1, 1]))
-    bvh = rt.BVH(tris)
-    assert sorted(bvh.triangleIndices) == list(range(len(tris)))
-    assert 1 <= bvh.nodesUsed <= 2 * len(tris) - 1
-    assert bvh.minCorner == [999999] * 3 and bvh.maxCorner == [-999999] * 3     # quirk: never updated (bvh.ts:23-25)
+# ---- bottom-level and top-level trees ------------------------------------------------------------------------
+def test_sah_tree_invariants():
+    soup = parse_obj(obj_uv_sphere(8, 12), dict(color=[1, 1, 1, 1]))
+    t = rt.build_tree(soup)
+    assert sorted(t.order) == list(range(soup.count)) and 1 <= t.used <= 2 * soup.count - 1
+    assert list(t.box_lo) == [999999] * 3 and list(t.box_hi) == [-999999] * 3      # quirk: never computed (bvh.ts:23-25)
     seen = set()
     def walk(i, depth):
-        nd = bvh.nodes[i]
-        if nd.primitiveCount == 0:
-            l = nd.leftChildIndex
+        if t.count[i] == 0:
+            l = int(t.first[i])
             for ch in (l, l + 1):
-                c = bvh.nodes[ch]
-                assert all(c.minCorner[k] >= nd.minCorner[k] and c.maxCorner[k] <= nd.maxCorner[k] for k in range(3))
+                assert np.all(t.lo[ch] >= t.lo[i]) and np.all(t.hi[ch] <= t.hi[i])
             return max(walk(l, depth + 1), walk(l + 1, depth + 1))
-        for j in range(nd.primitiveCount):
-            t = tris[bvh.triangleIndices[nd.leftChildIndex + j]]
-            seen.add(bvh.triangleIndices[nd.leftChildIndex + j])
-            for c in t.corners:
-                assert all(nd.minCorner[k] <= c[k] <= nd.maxCorner[k] for k in range(3))
+        for j in range(int(t.count[i])):
+            tri = int(t.order[t.first[i] + j])
+            seen.add(tri)
+            assert np.all(soup.position[tri] >= t.lo[i]) and np.all(soup.position[tri] <= t.hi[i])
         return depth
     depth = walk(0, 0)
-    assert seen == set(range(len(tris))) and depth < 20
+    assert seen == set(range(soup.count)) and depth < 20
+    rec = t.nodes(100, 5000)                                 # rebased records: children +100, leaf runs +5000
+    inner = t.count == 0
+    assert np.array_equal(rec[inner, 3], (t.first[inner] + 100).astype(F)) and np.array_equal(rec[~inner, 3], (t.first[~inner] + 5000).astype(F))
+
+
+def test_top_level_median_split():
+    lo = np.array([[0, 0, 0], [10, 0, 0], [20, 0, 0], [21, 0, 0]], float); hi = lo + 1
+    centre = ((lo + hi) / 2).astype(F)
+    nodes, lookup = top_level(lo, hi, centre)
+    assert nodes.shape == (7, 8) and sorted(lookup) == [0, 1, 2, 3]
+    assert nodes[0, 7] == 0 and nodes[0, 3] == 1 and list(nodes[0, 0:3]) == [0, 0, 0] and list(nodes[0, 4:7]) == [22, 1, 1]
+    leaves = nodes[nodes[:, 7] > 0]
+    assert leaves[:, 7].sum() == 4
+    one, _ = top_level(lo[:1], hi[:1], centre[:1])
+    assert one.shape == (1, 8) and one[0, 7] == 1
+    same, _ = top_level(lo[[0, 0, 0]], hi[[0, 0, 0]], centre[[0, 0, 0]])          # nothing separates: one leaf of three
+    assert same.shape == (1, 8) and same[0, 7] == 3
 
 
 def test_scene_layout_and_packing():
     scene, mat = triangle_scene(seed=3, n_models=3)
-    n_models = len(scene.models)
+    n_models = len(scene.instances)
     assert scene.tlasNodesMax == 2 * n_models - 1 and scene.tlasNodesUsed <= scene.tlasNodesMax
-    assert sorted(scene.blasIndices) == list(range(n_models))
-    assert len(scene.nodes) == scene.tlasNodesMax + scene.blasNodesUsed
-    assert sorted(scene.triangleIndices) == list(range(len(scene.triangles)))
+    assert sorted(scene.pack_blas_lookup()) == list(range(n_models))
+    assert sorted(scene.pack_tri_lookup()) == list(range(scene.triangleCount))
     b = tri_buffers(scene, mat)
-    assert b["triangles"].shape == (len(scene.triangles), 40) and b["blas"].shape == (n_models, 20)
+    assert b["nodes"].shape[0] == scene.tlasNodesMax + scene.blasNodesUsed
+    assert b["triangles"].shape == (scene.triangleCount, 40) and b["blas"].shape == (n_models, 20)
     # BLAS root indices point past the TLAS slots; inner BLAS nodes were rebased (SR:256-272)
     assert all(b["blas"][i, 16] >= scene.tlasNodesMax for i in range(n_models))
-    t0 = scene.triangles[0]
-    assert np.array_equal(b["triangles"][0, 0:3], np.array(t0.corners[0]).astype(F))
-    assert np.array_equal(b["triangles"][0, 36:40], np.array(t0.color).astype(F))
+    s0 = scene.meshes[0].soup
+    assert np.array_equal(b["triangles"][0, 0:3], s0.position[0, 0].astype(F))
+    assert np.array_equal(b["triangles"][0, 36:40], s0.color.astype(F))
     # TLAS boxes: the +-999999 placeholders through the model matrix (quirk kept)
     assert b["nodes"][0, 0] < -9e5 and b["nodes"][0, 4] > 9e5
-    # update(dt) rebuilds BLAS matrices and the TLAS
+    # update(dt) rebuilds instance matrices and the top-level tree
     before = scene.pack_blas().copy()
     scene.update(0.5)
     assert not np.array_equal(before, scene.pack_blas())

@@ -34,7 +34,7 @@ def test_triangle_scene_bit_exact(oracle, seed, W, H, B):
 
 def test_finer_meshes_deeper_trees(oracle):
     scene, mat = triangle_scene(seed=7, n_models=5, rings=24, sectors=32)
-    assert len(scene.triangles) > 3000
+    assert scene.triangleCount > 3000
     sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
     ref, _, rays = oracle.render_tri(scene.pack_params(4), tri_buffers(scene, mat), sky.faces, 480, 270)
     img, st = gpu_render_tri(scene, mat, 480, 270, 4, skybox=sky)

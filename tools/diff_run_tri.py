@@ -34,7 +34,7 @@ for seed in range(first, first + count):
     rays_total += rays
     if not ok:
         bad += 1
-        print("MISMATCH seed", seed, W, H, B, len(scene.triangles), diff_stats(img, ref), diff_stats(himg, href), flush=True)
+        print("MISMATCH seed", seed, W, H, B, scene.triangleCount, diff_stats(img, ref), diff_stats(himg, href), flush=True)
     if (seed - first) % 20 == 19:
         print("... %d scenes, %d mismatches, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
 print("diff_run_tri: %d scenes (seeds %d..%d), %d rays, mismatches %d, %.0f s" % (count, first, first + count - 1, rays_total, bad, time.time() - t0))

@@ -25,7 +25,7 @@ def main():
     a = ap.parse_args()
     t0 = time.time()
     scene, mat = triangle_scene(seed=21, n_models=2, rings=a.rings, sectors=a.sectors)
-    print("scene: %d triangles, %d nodes, built in %.1f s" % (len(scene.triangles), len(scene.nodes), time.time() - t0), flush=True)
+    print("scene: %d triangles, %d nodes, built in %.1f s" % (scene.triangleCount, scene.node_buffer_length(), time.time() - t0), flush=True)
     for heat in (False, True):
         r = rt.RendererRaytracing(a.width, a.height, scene, maxBounces=a.bounces).initialize(None, mat)
         if heat:
