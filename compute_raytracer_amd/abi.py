@@ -32,7 +32,12 @@ SYMBOLS = [
     "rt_build_hierarchy", "rt_filter_plan",
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_render_gather", "rt_frame_pixels", "rt_read_frame",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_ctx", "rt_group_render", "rt_group_wait",
+    "rt_build_id", "rt_kernel_name", "rt_set_comm_timeout",
 ]
+
+# rt_kernel_id (include/rt355.h): which kernel form rendered a frame
+KERNEL_IDS = {0: "none", 1: "literal", 2: "brute_single", 3: "brute_pipeline", 4: "hierarchy_8", 5: "hierarchy_12",
+              6: "hierarchy_16", 7: "hierarchy_global", 8: "triangles", 9: "heatmap"}
 
 
 class RtStats(ctypes.Structure):
@@ -42,6 +47,7 @@ class RtStats(ctypes.Structure):
         ("prep_ms", ctypes.c_float), ("frames", ctypes.c_uint32), ("mode", ctypes.c_int),
         ("batch_frames", ctypes.c_uint32), ("batch_kernel_ms", ctypes.c_float),
         ("gather_ms", ctypes.c_float), ("batch_gather_ms", ctypes.c_float),
+        ("kernel_id", ctypes.c_uint32), ("grid_share", ctypes.c_uint32), ("instance_uploads", ctypes.c_uint32),
     ]
 
 
@@ -131,6 +137,9 @@ def load():
         "rt_group_ctx": (vp, [vp, ctypes.c_int]),
         "rt_group_render": (ctypes.c_int, [vp, ctypes.c_int]),
         "rt_group_wait": (ctypes.c_int, [vp]),
+        "rt_build_id": (ctypes.c_char_p, []),
+        "rt_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
+        "rt_set_comm_timeout": (ctypes.c_int, [vp, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -18,6 +18,11 @@
 #include "rt_bvh_build.h"
 
 thread_local std::string g_rt_err;
+thread_local int g_rt_kernel_id = 0;
+
+#ifndef RT355_BUILD_ID
+#define RT355_BUILD_ID "unknown"
+#endif
 
 // Rebuilds the hierarchy's topology for moved spheres off the caller's thread.  rt_write_spheres with an
 // unchanged sphere count posts the new records here; frames meanwhile use the OLD topology with node
@@ -130,6 +135,23 @@ extern "C" {
 
 int rt_abi_version(void) { return RT355_ABI_VERSION; }
 
+const char* rt_build_id(void) { return RT355_BUILD_ID; }
+
+const char* rt_kernel_name(int id) {
+    switch (id) {
+        case RT_KID_LITERAL: return "trace_pixels<literal>";
+        case RT_KID_BRUTE_SINGLE: return "trace_pixels<filter>";
+        case RT_KID_BRUTE_PIPELINE: return "first_bounce+trace_paths";
+        case RT_KID_HIERARCHY_8: return "bvh_pixels<8>";
+        case RT_KID_HIERARCHY_12: return "bvh_pixels<12>";
+        case RT_KID_HIERARCHY_16: return "bvh_pixels<16>";
+        case RT_KID_HIERARCHY_GLOBAL: return "bvh_pixels<global>";
+        case RT_KID_TRIANGLES: return "trace_triangles";
+        case RT_KID_HEATMAP: return "heatmap_triangles";
+        default: return "none";
+    }
+}
+
 const char* rt_last_error(rt_ctx*) { return g_rt_err.c_str(); }
 
 int rt_create(int device, rt_ctx** out) {
@@ -194,8 +216,9 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
-    for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_nodes, &c->d_blas, &c->d_tri_lookup, &c->d_blas_lookup, &c->d_tex})
-        (void)hipFree(b->p);
+    for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex}) (void)hipFree(b->p);
+    for (int v = 0; v < kVersions; ++v)
+        for (rt_ctx::DevBuf* b : {&c->d_nodes[v], &c->d_blas[v], &c->d_blas_lookup[v]}) (void)hipFree(b->p);
     (void)hipFree(c->d_rays);
     if (c->h_rays) (void)hipHostFree(c->h_rays);
     for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) {
@@ -376,24 +399,30 @@ int rt_write_cubemap_face(rt_ctx* c, int face, uint32_t w, uint32_t h, const uin
     return RT_OK;
 }
 
+// capacity of a device buffer, contents kept; drains when it has to reallocate
+static int grow_buf(rt_ctx* c, rt_ctx::DevBuf& b, size_t need) {
+    if (need <= b.cap) return RT_OK;
+    { int rc = drain(c); if (rc != RT_OK) return rc; }
+    RT_HIP(hipStreamSynchronize(c->stream));
+    void* np = nullptr;
+    const size_t cap = need < 256 ? 256 : need;
+    RT_HIP(hipMalloc(&np, cap));
+    RT_HIP(hipMemsetAsync(np, 0, cap, c->stream));
+    if (b.p && b.used) RT_HIP(hipMemcpyAsync(np, b.p, b.used, hipMemcpyDeviceToDevice, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(b.p);
+    b.p = np;
+    b.cap = cap;
+    return RT_OK;
+}
+
 // writeBuffer(buffer, byte_offset, data): grows the device buffer when needed (keeping what is
 // already there), copies, and returns once the caller's memory is no longer needed
 static int write_buf(rt_ctx* c, rt_ctx::DevBuf& b, size_t byte_offset, const void* data, size_t bytes, const char* who) {
     RT_HIP(hipSetDevice(c->device));
     { int rc = drain(c); if (rc != RT_OK) return rc; }
     const size_t need = byte_offset + bytes;
-    if (need > b.cap) {
-        RT_HIP(hipStreamSynchronize(c->stream));
-        void* np = nullptr;
-        const size_t cap = need < 256 ? 256 : need;
-        RT_HIP(hipMalloc(&np, cap));
-        RT_HIP(hipMemsetAsync(np, 0, cap, c->stream));
-        if (b.p && b.used) RT_HIP(hipMemcpyAsync(np, b.p, b.used, hipMemcpyDeviceToDevice, c->stream));
-        RT_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(b.p);
-        b.p = np;
-        b.cap = cap;
-    }
+    { int rc = grow_buf(c, b, need); if (rc != RT_OK) return rc; }
     if (bytes) {
         if (!data) return fail(RT_ERR_INVALID_ARG, who);
         RT_HIP(hipMemcpyAsync(static_cast<char*>(b.p) + byte_offset, data, bytes, hipMemcpyHostToDevice, c->stream));
@@ -410,17 +439,63 @@ int rt_write_triangles(rt_ctx* c, const float* data, uint32_t n) {              
     if (rc == RT_OK) c->scene_kind = 1;
     return rc;
 }
+// The same write into every version of a per-frame buffer (the static part of the scene, or an instance set too large
+// to travel with a frame): drains, like every scene-setup call.
+static int write_versions(rt_ctx* c, rt_ctx::DevBuf (&b)[kVersions], size_t byte_offset, const void* data, size_t bytes, const char* who) {
+    for (int v = 0; v < kVersions; ++v) c->ver_gen[v] = 0;      // the next frame on each version re-applies the per-frame state
+    for (int v = 0; v < kVersions; ++v) {
+        int rc = write_buf(c, b[v], byte_offset, data, bytes, who);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+}
+// capacity for a per-frame write in every version, contents kept; drains only when something must grow
+static int reserve_versions(rt_ctx* c, rt_ctx::DevBuf (&b)[kVersions], size_t bytes) {
+    for (int v = 0; v < kVersions; ++v) {
+        if (b[v].cap < bytes) c->ver_gen[v] = 0;
+        int rc = grow_buf(c, b[v], bytes);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+}
+
 int rt_write_nodes(rt_ctx* c, size_t byte_offset, const float* data, uint32_t n) {    // RR:184-192, 212-223
     if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_nodes: NULL argument");
     if (byte_offset % 32u) return fail(RT_ERR_INVALID_ARG, "rt_write_nodes: byte_offset must be a multiple of the 32-byte node");
-    int rc = write_buf(c, c->d_nodes, byte_offset, data, (size_t)n * 32u, "rt_write_nodes: NULL data");
-    if (rc == RT_OK) c->scene_kind = 1;
+    const size_t bytes = (size_t)n * 32u, end = byte_offset + bytes;
+    const size_t head_bytes = (size_t)kHeadNodes * 32u;
+    // the part of the write that falls into the head region updates the host's copy of it; frames carry that copy
+    if (byte_offset < head_bytes && n) {
+        const size_t hi = std::min(end, head_bytes);
+        if (c->inst.head.size() < (size_t)kHeadNodes * 8u) c->inst.head.resize((size_t)kHeadNodes * 8u, 0.0f);
+        std::memcpy(reinterpret_cast<char*>(c->inst.head.data()) + byte_offset, data, hi - byte_offset);
+        c->inst.head_nodes = std::max(c->inst.head_nodes, (uint32_t)(hi / 32u));
+        ++c->inst.gen;
+    }
+    int rc = RT_OK;
+    if (end <= head_bytes) {                        // the per-frame TLAS write (RR:184-192): no drain, the next frame carries it
+        RT_HIP(hipSetDevice(c->device));
+        rc = reserve_versions(c, c->d_nodes, head_bytes);
+    } else {
+        rc = write_versions(c, c->d_nodes, byte_offset, data, bytes, "rt_write_nodes: NULL data");
+    }
+    if (rc == RT_OK) { c->scene_kind = 1; c->nodes_used = std::max(c->nodes_used, end); }
     return rc;
 }
 int rt_write_blas(rt_ctx* c, const float* data, uint32_t n) {                         // RR:169-174
     if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_blas: NULL argument");
-    c->d_blas.used = 0;
-    return write_buf(c, c->d_blas, 0, data, (size_t)n * 80u, "rt_write_blas: NULL data");
+    if (n <= kInstMax) {
+        RT_HIP(hipSetDevice(c->device));
+        int rc = reserve_versions(c, c->d_blas, (size_t)kInstMax * 80u);
+        if (rc != RT_OK) return rc;
+        c->inst.blas.assign(data, data + 20u * (size_t)n);
+        c->inst.blas_on = true;
+        ++c->inst.gen;
+        return RT_OK;
+    }
+    c->inst.blas_on = false;
+    for (int v = 0; v < kVersions; ++v) c->d_blas[v].used = 0;
+    return write_versions(c, c->d_blas, 0, data, (size_t)n * 80u, "rt_write_blas: NULL data");
 }
 int rt_write_tri_lookup(rt_ctx* c, const float* data, uint32_t n) {                   // RR:225-229
     if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_tri_lookup: NULL argument");
@@ -429,8 +504,18 @@ int rt_write_tri_lookup(rt_ctx* c, const float* data, uint32_t n) {             
 }
 int rt_write_blas_lookup(rt_ctx* c, const float* data, uint32_t n) {                  // RR:177-181
     if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_blas_lookup: NULL argument");
-    c->d_blas_lookup.used = 0;
-    return write_buf(c, c->d_blas_lookup, 0, data, (size_t)n * 4u, "rt_write_blas_lookup: NULL data");
+    if (n <= kInstMax) {
+        RT_HIP(hipSetDevice(c->device));
+        int rc = reserve_versions(c, c->d_blas_lookup, (size_t)kInstMax * 4u);
+        if (rc != RT_OK) return rc;
+        c->inst.lookup.assign(data, data + (size_t)n);
+        c->inst.lookup_on = true;
+        ++c->inst.gen;
+        return RT_OK;
+    }
+    c->inst.lookup_on = false;
+    for (int v = 0; v < kVersions; ++v) c->d_blas_lookup[v].used = 0;
+    return write_versions(c, c->d_blas_lookup, 0, data, (size_t)n * 4u, "rt_write_blas_lookup: NULL data");
 }
 int rt_write_mesh_texture(rt_ctx* c, uint32_t w, uint32_t h, const uint8_t* rgba) {   // material.ts:61-65
     if (!c || !rgba) return fail(RT_ERR_INVALID_ARG, "rt_write_mesh_texture: NULL argument");
@@ -468,7 +553,9 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     const bool tri = c->scene_kind == 1;
     if (!tri && !c->have_spheres) return fail(RT_ERR_STATE, "rt_render: rt_write_spheres has not been called");
     if (tri) {
-        if (!c->d_tri.used || !c->d_nodes.used || !c->d_blas.used || !c->d_tri_lookup.used || !c->d_blas_lookup.used)
+        const bool have_blas = c->inst.blas_on ? !c->inst.blas.empty() : c->d_blas[0].used != 0;
+        const bool have_lookup = c->inst.lookup_on ? !c->inst.lookup.empty() : c->d_blas_lookup[0].used != 0;
+        if (!c->d_tri.used || !c->nodes_used || !have_blas || !c->d_tri_lookup.used || !have_lookup)
             return fail(RT_ERR_STATE, "rt_render: a triangle scene needs rt_write_triangles, _nodes, _blas, _tri_lookup and _blas_lookup");
         if (!c->d_tex.used) {   // meshTex is mandatory in the reference (RR:113-114); default: 1x1 white
             const uint8_t white[4] = {255, 255, 255, 255};
@@ -491,7 +578,10 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     // end-of-frame tail is hidden: at 3840x2160 / 8 bounces the two forms cross at ~110 spheres one frame at a
     // time and at ~60 in flight (96 spheres: 1.33 vs 1.00 ms and 0.76 vs 0.98 ms; profiles/r02/count_sweep.log) --
     // or whenever variant 4 asks for it; variant 5 is the brute-force default, 1-3 its forms.
-    const uint32_t bvh_from = c->pipelined_hint ? 72u : 128u;
+    bool own_stream = false;                       // one of the streams rt_render / rt_render_gather rotate over
+    for (int k = 0; k < kStreams; ++k) own_stream = own_stream || s == c->streams[k];
+    const bool hint = own_stream && c->pipelined_hint;
+    const uint32_t bvh_from = hint ? 72u : 128u;
     const bool use_bvh = !tri && c->mode == RT_MODE_FAST && filter_ok && c->n > 0 &&
                          (c->variant == 4 || (c->variant == 0 && c->n >= bvh_from));
     // Frames in flight: the hierarchy kernel and the triangle kernels write nothing but their
@@ -621,9 +711,11 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             if (!known) seen[distinct++] = o;
         }
         fa.grid_share = distinct;
-        // a caller that has been enqueuing frames back to back gets equal shares from the first frame of a
-        // batch on (rt_bvh.hip: launch_bvh_as); one that waits after every frame keeps the whole chip
-        if (c->pipelined_hint) fa.grid_share = (uint32_t)kStreams;
+        // a caller that has been enqueuing frames back to back through rt_render / rt_render_gather (the library's
+        // own rotation over kStreams streams) gets equal shares from the first frame of a batch on (rt_bvh.hip:
+        // launch_bvh_as); one that waits after every frame keeps the whole chip, and frames a host enqueues on its
+        // own stream(s) through rt_render_to share the chip by the streams actually in use, whatever the history
+        if (hint) fa.grid_share = (uint32_t)kStreams;
     }
 
     // this frame's partial ray counters and its 32-byte control block: one of RT355_MAX_IN_FLIGHT
@@ -647,20 +739,41 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     cfg.mode = filter_ok ? c->mode : (int)RT_MODE_STRICT;
     cfg.variant = (c->variant == 4 || c->variant == 5) ? 0 : c->variant;   // rt_kernels.hip numbers its default 0
 
+    // Per-frame instance data (RR:169-192) travels with the frame: version `v` of the three buffers is brought to the
+    // host's current state by a one-workgroup kernel whose kernarg block holds the values, in front of the ray-trace
+    // kernel on the frame's stream.  The frame kVersions slots back read the same version: it must be through.
+    const uint32_t v = slot % (uint32_t)kVersions;
+    if (tri && c->ver_gen[v] != c->inst.gen) {
+        if (slot >= (uint32_t)kVersions) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[slot - (uint32_t)kVersions], 0));
+        RtInstanceArgs ia;
+        ia.nodes = static_cast<float*>(c->d_nodes[v].p);
+        ia.blas = static_cast<float*>(c->d_blas[v].p);
+        ia.lookup = static_cast<float*>(c->d_blas_lookup[v].p);
+        ia.n_head_f = ia.nodes ? c->inst.head_nodes * 8u : 0u;
+        ia.n_blas_f = (c->inst.blas_on && ia.blas) ? (uint32_t)c->inst.blas.size() : 0u;
+        ia.n_lookup_f = (c->inst.lookup_on && ia.lookup) ? (uint32_t)c->inst.lookup.size() : 0u;
+        if (ia.n_head_f) std::memcpy(ia.data, c->inst.head.data(), ia.n_head_f * sizeof(float));
+        if (ia.n_blas_f) std::memcpy(ia.data + 31 * 8, c->inst.blas.data(), ia.n_blas_f * sizeof(float));
+        if (ia.n_lookup_f) std::memcpy(ia.data + 31 * 8 + 16 * 20, c->inst.lookup.data(), ia.n_lookup_f * sizeof(float));
+        RT_HIP(rt_launch_apply_instances(ia, s));
+        c->ver_gen[v] = c->inst.gen;
+        ++c->stats.instance_uploads;
+    }
     RT_HIP(hipEventRecord(c->ev_k0[slot], s));
+    g_rt_kernel_id = RT_KID_NONE;
     if (tri) {
         RtTriScene ts;
-        ts.nodes = static_cast<const float4*>(c->d_nodes.p);
-        ts.blas = static_cast<const float*>(c->d_blas.p);
+        ts.nodes = static_cast<const float4*>(c->d_nodes[v].p);
+        ts.blas = static_cast<const float*>(c->d_blas[v].p);
         ts.tri = static_cast<const float*>(c->d_tri.p);
         ts.tri_lookup = static_cast<const float*>(c->d_tri_lookup.p);
-        ts.blas_lookup = static_cast<const float*>(c->d_blas_lookup.p);
+        ts.blas_lookup = static_cast<const float*>(c->d_blas_lookup[v].p);
         ts.tex = static_cast<const uint8_t*>(c->d_tex.p);
-        ts.n_nodes = (uint32_t)(c->d_nodes.used / 32u);
-        ts.n_blas = (uint32_t)(c->d_blas.used / 80u);
+        ts.n_nodes = (uint32_t)(c->nodes_used / 32u);
+        ts.n_blas = c->inst.blas_on ? (uint32_t)(c->inst.blas.size() / 20u) : (uint32_t)(c->d_blas[v].used / 80u);
         ts.n_tri = (uint32_t)(c->d_tri.used / 160u);
         ts.n_tri_lookup = (uint32_t)(c->d_tri_lookup.used / 4u);
-        ts.n_blas_lookup = (uint32_t)(c->d_blas_lookup.used / 4u);
+        ts.n_blas_lookup = c->inst.lookup_on ? (uint32_t)c->inst.lookup.size() : (uint32_t)(c->d_blas_lookup[v].used / 4u);
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
     } else {
@@ -668,6 +781,8 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
+    c->stats.kernel_id = (uint32_t)g_rt_kernel_id;
+    c->stats.grid_share = fa.grid_share;
     c->in_flight = slot + 1;
     return RT_OK;
 }
@@ -691,10 +806,30 @@ int rt_render_to(rt_ctx* c, void* device_dst, size_t cap, void* hip_stream) {
     return rt_enqueue(c, static_cast<uint8_t*>(device_dst), s);
 }
 
+// forget the frames in flight (their work has left the device: a communicator was aborted): counters zeroed, ring empty
+void rt_abandon_in_flight(rt_ctx* c) {
+    for (int k = 0; k < kStreams; ++k)
+        if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
+    if (c->in_flight) {
+        (void)hipMemsetAsync(c->d_rays, 0, kCtrlBytes * c->in_flight, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    (void)hipGetLastError();
+    c->in_flight = 0;
+    c->stats.batch_frames = 0;
+    for (int v = 0; v < kVersions; ++v) c->ver_gen[v] = 0;
+}
+
 int rt_wait(rt_ctx* c) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_wait: ctx is NULL");
     RT_HIP(hipSetDevice(c->device));
-    for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipEventSynchronize(c->ev_k1[i]));
+    if (c->comm && c->in_flight) {
+        // frames that end in an RCCL exchange: a poll that notices a failed peer or a missed deadline (rt_comm.hip)
+        int rc = rt_comm_wait_frames(c);
+        if (rc != RT_OK) return rc;
+    } else {
+        for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipEventSynchronize(c->ev_k1[i]));
+    }
     if (c->in_flight) {
         // ray count of the latest frame; then the counter sets of this batch are zeroed for the next
         RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays + (kCtrlBytes / 8u) * (c->in_flight - 1u), kCounterBytes,
@@ -705,7 +840,17 @@ int rt_wait(rt_ctx* c) {
         c->stats.rays = 0;
         for (uint32_t k = 0; k < RT_RAY_COUNTERS; ++k) c->stats.rays += c->h_rays[k * (RT_RAY_COUNTER_STRIDE / 8u)];
         c->stats.batch_frames = c->in_flight;
-        c->pipelined_hint = c->in_flight > 1u;
+        // Frames in flight?  Only the library's own rotation counts: a host that enqueues several frames on ONE stream
+        // of its own (rt_render_to) has them serialised by that stream, and must not be given a quarter of the chip.
+        {
+            uint32_t distinct = 0;
+            for (int k = 0; k < kStreams; ++k) {
+                bool used = false;
+                for (uint32_t i = 0; i < c->in_flight; ++i) used = used || c->slot_stream[i] == c->streams[k];
+                distinct += used ? 1u : 0u;
+            }
+            c->pipelined_hint = distinct > 1u;
+        }
         c->stats.batch_kernel_ms = 0.0f;
         for (uint32_t i = 0; i < c->in_flight; ++i) {
             float ms = 0.0f;
@@ -717,6 +862,14 @@ int rt_wait(rt_ctx* c) {
         }
         (void)hipGetLastError();
         c->in_flight = 0;
+        // a kernel that could not run as planned says so in the word behind its first ray counter (rt_device.h: report_fault)
+        const unsigned long long fault = c->h_rays[1];
+        if (fault != 0ull) {
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "rt_wait: the ray-trace kernel reported fault %llu (1: dynamic LDS not at address 0); the frame is incomplete", fault);
+            g_rt_err = buf;
+            return RT_ERR_HIP;
+        }
         return rt_comm_after_wait(c);
     }
     return RT_OK;

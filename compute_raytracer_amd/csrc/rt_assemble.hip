@@ -32,3 +32,20 @@ hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t 
     }
     return hipGetLastError();
 }
+
+// Per-frame instance data of a triangle scene (RR:169-192: BLAS records, BLAS lookup, TLAS nodes): the values travel
+// in this kernel's kernarg block -- copied by the runtime when the launch is enqueued, so the host may rewrite its own
+// copy at once -- and are stored into the buffer versions the frame behind it on the same stream reads.  One
+// workgroup; the three destinations are a few hundred floats.
+__global__ __launch_bounds__(256) void apply_instances(const RtInstanceArgs a) {
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < a.n_head_f; i += 256u) a.nodes[i] = a.data[i];
+    for (uint32_t i = t; i < a.n_blas_f; i += 256u) a.blas[i] = a.data[31u * 8u + i];
+    for (uint32_t i = t; i < a.n_lookup_f; i += 256u) a.lookup[i] = a.data[31u * 8u + 16u * 20u + i];
+}
+
+hipError_t rt_launch_apply_instances(const RtInstanceArgs& a, hipStream_t s) {
+    if (a.n_head_f + a.n_blas_f + a.n_lookup_f == 0u) return hipSuccess;
+    hipLaunchKernelGGL(apply_instances, dim3(1), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

@@ -406,7 +406,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
     float4* sR = reinterpret_cast<float4*>(lds_b + (NLDS ? 4u * (base + l0off) - base : 0u));
     uint32_t* lists = reinterpret_cast<uint32_t*>(lds_b + (NLDS ? bvh_lds_lists(n, base) : 1024u));
     (void)n4;
-    if (NLDS && base != 0u) return;      // the host sized the allocation for dynamic LDS at address 0 (no static LDS in this kernel)
+    // the host sized the allocation for dynamic LDS at address 0 (no static LDS in this kernel); anything else is
+    // reported, not rendered: rt_wait fails the frame (rt_device.h: report_fault)
+    if (NLDS && base != 0u) { report_fault(A.rays, 1ull); return; }
     if (NLDS)
         for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) {
             float4 r = A.bvh_rec[i];
@@ -673,6 +675,7 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     }
 #endif
     if (!a.sky_flat && !a.fin) return hipErrorInvalidValue;
+    g_rt_kernel_id = !NLDS ? RT_KID_HIERARCHY_GLOBAL : (WAVES == 8 ? RT_KID_HIERARCHY_8 : (WAVES == 12 ? RT_KID_HIERARCHY_12 : RT_KID_HIERARCHY_16));
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
     if (!a.sky_flat) {
         const uint32_t slots = a.n_local_tiles * 8u * a.W;

@@ -19,8 +19,12 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstring>
 #include <new>
+#include <thread>
+
+#include "rt_wait_poll.h"
 
 struct rt_comm_state {
     ncclComm_t comm = nullptr;
@@ -33,6 +37,12 @@ struct rt_comm_state {
     hipEvent_t ev_r1[RT355_MAX_IN_FLIGHT] = {nullptr};   // end of the render, before the exchange
     hipEvent_t ev_x1[RT355_MAX_IN_FLIGHT] = {nullptr};   // end of the exchange, before the de-interleave
     bool slot_gathered[RT355_MAX_IN_FLIGHT] = {false};
+    uint32_t latest_w = 0, latest_h = 0;   // target size the latest frame was assembled for
+    // failure handling: a call that failed half way, an asynchronous RCCL error or a missed deadline leaves the
+    // communicator unusable; every collective entry point then returns RT_ERR_COMM until it is destroyed
+    bool poisoned = false;
+    uint32_t timeout_ms = 0;               // rt_set_comm_timeout
+    ncclComm_t* group_slot = nullptr;      // rt_group: where the group keeps this communicator (cleared on abort)
 };
 
 static int fail_nccl(ncclResult_t r, const char* where) {
@@ -49,7 +59,11 @@ static int fail_nccl(ncclResult_t r, const char* where) {
 
 static size_t message_bytes(const rt_ctx* c) { return (size_t)rt_padded_tiles(c->H, c->world) * 8u * c->W * 4u; }
 
-static void free_buffers(rt_comm_state* s) {
+static void free_buffers(rt_ctx* c) {
+    rt_comm_state* s = c->comm;
+    // rt_read_pixels / rt_device_pixels may be pointing into a gather buffer (the root renders straight into its slot)
+    for (int k = 0; k < kStreams; ++k)
+        if (s->d_gather[k] && c->d_out >= s->d_gather[k] && c->d_out < s->d_gather[k] + s->gather_bytes) c->d_out = c->d_outs[0];
     for (int k = 0; k < kStreams; ++k) {
         (void)hipFree(s->d_gather[k]); s->d_gather[k] = nullptr;
         (void)hipFree(s->d_frame[k]); s->d_frame[k] = nullptr;
@@ -62,7 +76,7 @@ static void free_buffers(rt_comm_state* s) {
 void rt_comm_release(rt_ctx* c) {
     rt_comm_state* s = c->comm;
     if (!s) return;
-    free_buffers(s);
+    free_buffers(c);
     for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i)
         if (s->ev_r1[i]) (void)hipEventDestroy(s->ev_r1[i]);
     for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i)
@@ -98,6 +112,51 @@ int rt_comm_after_wait(rt_ctx* c) {
     return RT_OK;
 }
 
+// Aborts the communicator (the exchange kernels leave the device), waits for what is left on the streams and
+// forgets the frames in flight.  The context stays valid for rt_comm_destroy / rt_destroy / single-GPU rendering.
+static void abort_comm(rt_ctx* c) {
+    rt_comm_state* s = c->comm;
+    s->poisoned = true;
+    if (s->comm) {
+        (void)ncclCommAbort(s->comm);
+        if (s->group_slot) *s->group_slot = nullptr;
+        s->comm = nullptr;
+    }
+    for (int i = 0; i < RT355_MAX_IN_FLIGHT; ++i) s->slot_gathered[i] = false;
+    s->latest = -1;
+    s->latest_has_frame = false;
+    rt_abandon_in_flight(c);
+}
+
+int rt_comm_wait_frames(rt_ctx* c) {
+    rt_comm_state* s = c->comm;
+    hipError_t hip_err = hipSuccess;
+    ncclResult_t async = ncclSuccess;
+    const RtPollVerdict v = rt_poll_until(
+        c->in_flight, s->timeout_ms,
+        [&](uint32_t i) {
+            const hipError_t e = hipEventQuery(c->ev_k1[i]);
+            if (e == hipSuccess) return true;
+            if (e != hipErrorNotReady) { hip_err = e; return true; }      // reported below
+            (void)hipGetLastError();
+            return false;
+        },
+        [&]() {
+            if (!s->comm || s->poisoned) return s->poisoned;
+            ncclResult_t r = ncclSuccess;
+            if (ncclCommGetAsyncError(s->comm, &r) != ncclSuccess) { async = ncclSystemError; return true; }
+            if (r != ncclSuccess && r != ncclInProgress) { async = r; return true; }
+            return false;
+        },
+        []() { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); },
+        []() { std::this_thread::yield(); });
+    if (hip_err != hipSuccess) return fail_hip(hip_err, "rt_wait: hipEventQuery");
+    if (v == RtPollVerdict::Done) return RT_OK;
+    abort_comm(c);
+    if (v == RtPollVerdict::Timeout) return fail(RT_ERR_COMM, "rt_wait: the frames did not complete within the communicator's deadline (rt_set_comm_timeout); communicator aborted");
+    return fail_nccl(async, "rt_wait: asynchronous RCCL error; communicator aborted");
+}
+
 static int attach(rt_ctx* c, ncclComm_t comm, bool owns, uint32_t rank, uint32_t world) {
     rt_comm_state* s = new (std::nothrow) rt_comm_state();
     if (!s) return fail(RT_ERR_HIP, "rt_comm_init: out of host memory");
@@ -125,7 +184,7 @@ static int ensure_buffers(rt_ctx* c, bool receives) {
     const size_t gb = message_bytes(c) * c->world, fb = (size_t)c->H * c->W * 4u;
     if (gb <= s->gather_bytes && fb <= s->frame_bytes && s->d_gather[0] && s->d_frame[0]) return RT_OK;
     { int rc = rt_drain(c); if (rc != RT_OK) return rc; }
-    free_buffers(s);
+    free_buffers(c);
     for (int k = 0; k < kStreams; ++k) {
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_gather[k]), gb));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_frame[k]), fb));
@@ -191,6 +250,7 @@ static int finish_part(rt_ctx* c, int root, uint32_t k, uint8_t* part) {
     RT_HIP(hipEventRecord(c->ev_k1[c->in_flight - 1u], st));
     s->latest = (int)k;
     s->latest_has_frame = receives;
+    s->latest_w = c->W; s->latest_h = c->H;
     c->d_out = part;       // rt_read_pixels / rt_device_pixels keep returning THIS rank's tiles
     ++c->frames_rendered;
     return RT_OK;
@@ -199,6 +259,7 @@ static int finish_part(rt_ctx* c, int root, uint32_t k, uint8_t* part) {
 static int check_gather_args(rt_ctx* c, int root, const char* who) {
     if (!c) return fail(RT_ERR_INVALID_ARG, who);
     if (!c->comm) return fail(RT_ERR_STATE, "rt_render_gather: no communicator (rt_comm_init / rt_group_create first)");
+    if (c->comm->poisoned) return fail(RT_ERR_COMM, "rt_render_gather: the communicator failed earlier (an RCCL error, a missed deadline or a call that failed half way); destroy it");
     if (root < -1 || root >= (int)c->world) return fail(RT_ERR_INVALID_ARG, "rt_render_gather: root must be -1 (all ranks) or a rank");
     if (!c->W || !c->H) return fail(RT_ERR_STATE, "rt_render_gather: rt_resize has not been called");
     return RT_OK;
@@ -247,26 +308,52 @@ int rt_comm_destroy(rt_ctx* c) {
     return rt_set_partition(c, 0, 1);
 }
 
-int rt_render_gather(rt_ctx* c, int root) {
-    { int rc = check_gather_args(c, root, "rt_render_gather: ctx is NULL"); if (rc != RT_OK) return rc; }
-    if (!c->comm->owns_comm) return fail(RT_ERR_STATE, "rt_render_gather: this context belongs to an rt_group; call rt_group_render");
+// Everything that can be refused BEFORE anything is enqueued: arguments, state, and the buffers of a receiving rank.
+static int prepare_gather(rt_ctx* c, int root, const char* who) {
+    { int rc = check_gather_args(c, root, who); if (rc != RT_OK) return rc; }
     RT_HIP(hipSetDevice(c->device));
+    return ensure_buffers(c, root < 0 || (uint32_t)root == c->rank);
+}
+
+// From the render's enqueue to the end event every step must happen on every rank, or the ranks' collectives no
+// longer pair up: a failure in between poisons the communicator (the peers find out through their deadline).
+static int poison(rt_ctx* c, int rc) {
+    if (rc != RT_OK && c->comm) c->comm->poisoned = true;
+    return rc;
+}
+
+int rt_render_gather(rt_ctx* c, int root) {
+    { int rc = prepare_gather(c, root, "rt_render_gather: ctx is NULL"); if (rc != RT_OK) return rc; }
+    if (!c->comm->owns_comm) return fail(RT_ERR_STATE, "rt_render_gather: this context belongs to an rt_group; call rt_group_render");
     const uint32_t k = c->frames_rendered % (uint32_t)kStreams;
     uint8_t* part = nullptr;
-    { int rc = render_part(c, root, k, &part); if (rc != RT_OK) return rc; }
-    { int rc = order_exchange(c, k); if (rc != RT_OK) return rc; }
-    RT_NCCL(ncclGroupStart());
+    {
+        const uint32_t before = c->in_flight;          // a render that failed before it enqueued anything leaves the group intact
+        int rc = render_part(c, root, k, &part);
+        if (rc != RT_OK) return c->in_flight != before ? poison(c, rc) : rc;
+    }
+    { int rc = order_exchange(c, k); if (rc != RT_OK) return poison(c, rc); }
+    { ncclResult_t r = ncclGroupStart(); if (r != ncclSuccess) return poison(c, fail_nccl(r, "ncclGroupStart")); }
     int rc = exchange_part(c, root, k, part);
     ncclResult_t ge = ncclGroupEnd();
-    if (rc != RT_OK) return rc;
-    if (ge != ncclSuccess) return fail_nccl(ge, "ncclGroupEnd");
-    return finish_part(c, root, k, part);
+    if (rc != RT_OK) return poison(c, rc);
+    if (ge != ncclSuccess) return poison(c, fail_nccl(ge, "ncclGroupEnd"));
+    return poison(c, finish_part(c, root, k, part));
+}
+
+int rt_set_comm_timeout(rt_ctx* c, uint32_t ms) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_set_comm_timeout: ctx is NULL");
+    if (!c->comm) return fail(RT_ERR_STATE, "rt_set_comm_timeout: no communicator (rt_comm_init / rt_group_create first)");
+    c->comm->timeout_ms = ms;
+    return RT_OK;
 }
 
 int rt_frame_pixels(rt_ctx* c, void** out_ptr, size_t* out_bytes) {
     if (!c || !out_ptr || !out_bytes) return fail(RT_ERR_INVALID_ARG, "rt_frame_pixels: NULL argument");
     if (!c->comm || c->comm->latest < 0) return fail(RT_ERR_STATE, "rt_frame_pixels: no rt_render_gather yet");
     if (!c->comm->latest_has_frame) return fail(RT_ERR_STATE, "rt_frame_pixels: this rank did not receive the frame (it is not the root)");
+    if (c->comm->latest_w != c->W || c->comm->latest_h != c->H || (size_t)c->H * c->W * 4u > c->comm->frame_bytes)
+        return fail(RT_ERR_STATE, "rt_frame_pixels: the target was resized after the latest rt_render_gather");
     *out_ptr = c->comm->d_frame[c->comm->latest];
     *out_bytes = (size_t)c->H * c->W * 4u;
     return RT_OK;
@@ -308,11 +395,12 @@ int rt_group_create(int n_devices, rt_group** out) {
     std::vector<int> devs((size_t)n_devices);
     for (int d = 0; d < n_devices; ++d) devs[(size_t)d] = d;
     ncclResult_t r = ncclCommInitAll(g->comms.data(), n_devices, devs.data());
-    if (r != ncclSuccess) { g->comms.clear(); rt_group_destroy(g); return fail_nccl(r, "ncclCommInitAll"); }
+    if (r != ncclSuccess) { rt_group_destroy(g); return fail_nccl(r, "ncclCommInitAll"); }   // whatever it did create is destroyed
     for (int d = 0; d < n_devices; ++d) {
         (void)hipSetDevice(d);
         int rc = attach(g->ctx[(size_t)d], g->comms[(size_t)d], false, (uint32_t)d, (uint32_t)n_devices);
         if (rc != RT_OK) { rt_group_destroy(g); return rc; }
+        g->ctx[(size_t)d]->comm->group_slot = &g->comms[(size_t)d];
     }
     *out = g;
     return RT_OK;
@@ -339,34 +427,47 @@ int rt_group_render(rt_group* g, int root) {
     const size_t n = g->ctx.size();
     std::vector<uint8_t*> part(n, nullptr);
     std::vector<uint32_t> k(n, 0u);
+    // every member is checked (arguments, state, buffers) before anything is enqueued on any
+    for (size_t d = 0; d < n; ++d) { int rc = prepare_gather(g->ctx[d], root, "rt_group_render: ctx is NULL"); if (rc != RT_OK) return rc; }
+    // from here on a failure leaves the members at different points of the collective sequence: the whole group is poisoned
+    auto poison_all = [&](int rc) { if (rc != RT_OK) for (rt_ctx* m : g->ctx) if (m->comm) m->comm->poisoned = true; return rc; };
     for (size_t d = 0; d < n; ++d) {
         rt_ctx* c = g->ctx[d];
-        { int rc = check_gather_args(c, root, "rt_group_render: ctx is NULL"); if (rc != RT_OK) return rc; }
-        RT_HIP(hipSetDevice(c->device));
+        { hipError_t e = hipSetDevice(c->device); if (e != hipSuccess) return poison_all(fail_hip(e, "hipSetDevice")); }
         k[d] = c->frames_rendered % (uint32_t)kStreams;
-        { int rc = render_part(c, root, k[d], &part[d]); if (rc != RT_OK) return rc; }
-        { int rc = order_exchange(c, k[d]); if (rc != RT_OK) return rc; }
+        {
+            const uint32_t before = c->in_flight;
+            int rc = render_part(c, root, k[d], &part[d]);
+            if (rc != RT_OK) return (d == 0 && c->in_flight == before) ? rc : poison_all(rc);
+        }
+        { int rc = order_exchange(c, k[d]); if (rc != RT_OK) return poison_all(rc); }
     }
-    RT_NCCL(ncclGroupStart());
+    { ncclResult_t r = ncclGroupStart(); if (r != ncclSuccess) return poison_all(fail_nccl(r, "ncclGroupStart")); }
     int rc = RT_OK;
     for (size_t d = 0; d < n && rc == RT_OK; ++d) {
         (void)hipSetDevice(g->ctx[d]->device);
         rc = exchange_part(g->ctx[d], root, k[d], part[d]);
     }
     ncclResult_t ge = ncclGroupEnd();
-    if (rc != RT_OK) return rc;
-    if (ge != ncclSuccess) return fail_nccl(ge, "ncclGroupEnd");
+    if (rc != RT_OK) return poison_all(rc);
+    if (ge != ncclSuccess) return poison_all(fail_nccl(ge, "ncclGroupEnd"));
     for (size_t d = 0; d < n; ++d) {
-        RT_HIP(hipSetDevice(g->ctx[d]->device));
-        { int rc2 = finish_part(g->ctx[d], root, k[d], part[d]); if (rc2 != RT_OK) return rc2; }
+        { hipError_t e = hipSetDevice(g->ctx[d]->device); if (e != hipSuccess) return poison_all(fail_hip(e, "hipSetDevice")); }
+        { int rc2 = finish_part(g->ctx[d], root, k[d], part[d]); if (rc2 != RT_OK) return poison_all(rc2); }
     }
     return RT_OK;
 }
 
 int rt_group_wait(rt_group* g) {
     if (!g) return fail(RT_ERR_INVALID_ARG, "rt_group_wait: group is NULL");
-    for (rt_ctx* c : g->ctx) { int rc = rt_wait(c); if (rc != RT_OK) return rc; }
-    return RT_OK;
+    int first = RT_OK;
+    std::string msg;
+    for (rt_ctx* c : g->ctx) {       // every member is waited for (or aborted) even when one fails
+        int rc = rt_wait(c);
+        if (rc != RT_OK && first == RT_OK) { first = rc; msg = g_rt_err; }
+    }
+    if (first != RT_OK) g_rt_err = msg;
+    return first;
 }
 
 }  // extern "C"

@@ -33,6 +33,9 @@ inline int fail_hip(hipError_t e, const char* where) {
 // frame, 0.45 of 0.8 ms when 8 ranks share the frame).  Frames in flight each take a share of the
 // chip (RtFrameArgs::grid_share), so one frame's tail runs beside the others' bulk.
 constexpr int kStreams = 4;
+constexpr int kVersions = 4;         // versions of the per-frame instance buffers (>= kStreams)
+constexpr uint32_t kHeadNodes = 31u; // TLAS nodes (2 M - 1 for M <= 16 instances) that travel with a frame
+constexpr uint32_t kInstMax = 16u;   // instances whose records travel with a frame
 constexpr size_t kCounterBytes = (size_t)RT_RAY_COUNTERS * RT_RAY_COUNTER_STRIDE;   // partial ray counters of one frame
 constexpr size_t kCtrlBytes = kCounterBytes + 32u;                                   // + the 32-byte control block
 
@@ -49,7 +52,8 @@ struct rt_ctx {
     uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
     hipStream_t slot_stream[RT355_MAX_IN_FLIGHT] = {nullptr};   // the stream each of them was enqueued on
     uint32_t frames_rendered = 0;        // rt_render calls: parity selects stream and colour buffer
-    bool pipelined_hint = false;         // the last rt_wait completed more than one frame: the caller keeps frames in flight
+    bool pipelined_hint = false;         // the last rt_wait completed frames on MORE THAN ONE of the library's own streams
+                                         // (rt_render / rt_render_gather back to back): the caller keeps frames in flight
     uint32_t W = 0, H = 0;
     uint32_t rank = 0, world = 1;
     float params[24] = {0};
@@ -90,7 +94,19 @@ struct rt_ctx {
     unsigned long long* h_rays = nullptr;  // pinned copy of the latest frame's partial counters
     // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
     struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };
-    DevBuf d_tri, d_nodes, d_blas, d_tri_lookup, d_blas_lookup, d_tex;
+    DevBuf d_tri, d_tri_lookup, d_tex;
+    // The buffers the reference rewrites before every frame (RR:169-192: BLAS records, BLAS lookup, the TLAS nodes at
+    // the head of the node buffer) exist in kVersions versions: a frame in flight keeps reading the version it was
+    // enqueued with while the host already writes the next state (rt_api.hip: apply_instances).
+    DevBuf d_nodes[kVersions], d_blas[kVersions], d_blas_lookup[kVersions];
+    struct {
+        std::vector<float> head, blas, lookup;   // current contents: first head_nodes nodes, BLAS records, BLAS lookup
+        uint32_t head_nodes = 0;                 // extent of the node buffer's head that per-frame writes have touched
+        bool blas_on = false, lookup_on = false; // the last write of that buffer was a per-frame (small) one
+        uint64_t gen = 0;                        // bumped by every per-frame write
+    } inst;
+    uint64_t ver_gen[kVersions] = {0, 0, 0, 0};  // inst.gen each device version holds
+    size_t nodes_used = 0;                       // bytes of the node buffer written so far (any version)
     uint32_t tex_w = 0, tex_h = 0;
     int scene_kind = 0;                    // 0 spheres, 1 triangles: the primitive type written last
     int mode = RT_MODE_FAST;
@@ -106,9 +122,11 @@ extern "C" {
 RT_INTERNAL int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s);   // prep + ray-trace launches of one frame into `dst` on `s`
 RT_INTERNAL int rt_drain(rt_ctx* c);                                  // waits for the frames in flight
 RT_INTERNAL uint32_t rt_local_tiles(const rt_ctx* c);
+RT_INTERNAL void rt_abandon_in_flight(rt_ctx* c);                     // after a communicator abort: forget the frames in flight
 }
 // rt_comm.hip
 RT_INTERNAL void rt_comm_release(rt_ctx* c);                          // called by rt_destroy
 RT_INTERNAL int rt_comm_after_wait(rt_ctx* c);                        // called by rt_wait once the frames in flight are complete
+RT_INTERNAL int rt_comm_wait_frames(rt_ctx* c);                       // called by rt_wait: polls the frames' events and the communicator
 
 

@@ -154,8 +154,11 @@ __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = 
     if (A.sky_seamless && x0 >= 0 && x0 + 1 < w && y0 >= 0 && y0 + 1 < w) {
         // all four taps on the selected face (all but one sample in a few hundred): the tap pairs of a row are
         // adjacent texels, one 8-byte load each; same lerps as below
-        const uint2 r0 = *reinterpret_cast<const uint2*>(f + 4u * ((size_t)y0 * (size_t)w + (size_t)x0));
-        const uint2 r1 = *reinterpret_cast<const uint2*>(f + 4u * ((size_t)(y0 + 1) * (size_t)w + (size_t)x0));
+        // (two 4-byte-aligned texels: memcpy leaves the width of the load to the compiler -- an 8-byte access at an
+        // odd texel would be undefined in C++, even where the hardware's unaligned mode serves it)
+        uint2 r0, r1;
+        __builtin_memcpy(&r0, f + 4u * ((size_t)y0 * (size_t)w + (size_t)x0), 8);
+        __builtin_memcpy(&r1, f + 4u * ((size_t)(y0 + 1) * (size_t)w + (size_t)x0), 8);
         auto un = [&](uint32_t p) {
             if (lut) return V(lut[p & 255u], lut[(p >> 8) & 255u], lut[(p >> 16) & 255u]);
             return V((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f);
@@ -247,6 +250,13 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // counters 256 B apart (the host adds them up): atomics on ONE address complete about 12 ns apart,
 // and a 4K frame of the triangle kernels ends 129,600 waves, each with its atomic: 1.57 ms, which
 // WAS the frame time of those kernels whatever else changed.
+// A kernel that finds it cannot run as the host planned says so in the word behind the frame's first ray counter
+// (the partial sums are RT_RAY_COUNTER_STRIDE apart, the bytes between them are free); rt_wait turns a non-zero
+// word into RT_ERR_HIP instead of handing out a frame that was never written.
+__device__ __forceinline__ void report_fault(unsigned long long* counter, unsigned long long code) {
+    if (threadIdx.x == 0) atomicMax(counter + 1, code);
+}
+
 __device__ __forceinline__ void count_rays(unsigned long long* counter, uint32_t nrays) {
     const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     unsigned long long* part = counter + (size_t)(wave_id % RT_RAY_COUNTERS) * (RT_RAY_COUNTER_STRIDE / 8u);

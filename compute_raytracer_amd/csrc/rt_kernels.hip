@@ -664,6 +664,7 @@ hipError_t launch_paths(const RtFrameArgs& a, hipStream_t s) {
     uint32_t blocks = 256u * (per_cu ? per_cu : 1u);
     const uint32_t need = (pixels + 64u * WAVES - 1u) / (64u * WAVES);
     if (blocks > need) blocks = need;
+    g_rt_kernel_id = RT_KID_BRUTE_PIPELINE;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
     return hipGetLastError();
 }
@@ -754,7 +755,8 @@ hipError_t launch_fast(const RtFrameArgs& a, int variant, hipStream_t s) {
 }  // namespace rtk
 
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s) {
-    if (cfg.mode == 1) return rtk::launch_strict(a, s);
+    if (cfg.mode == 1) { g_rt_kernel_id = RT_KID_LITERAL; return rtk::launch_strict(a, s); }
+    g_rt_kernel_id = RT_KID_BRUTE_SINGLE;          // launch_paths overrides it when the two-kernel pipeline runs
     return a.signed_filter ? rtk::launch_fast<true>(a, cfg.variant, s) : rtk::launch_fast<false>(a, cfg.variant, s);
 }
 

@@ -383,6 +383,7 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, h
 
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    g_rt_kernel_id = heatmap ? RT_KID_HEATMAP : RT_KID_TRIANGLES;
     if (t.n_nodes <= 65536u) launch_tri<uint16_t, 4>(a, t, heatmap, s);
     else                     launch_tri<uint32_t, 3>(a, t, heatmap, s);      // 44 KB of stacks: three workgroups per CU
     return hipGetLastError();

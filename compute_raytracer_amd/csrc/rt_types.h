@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/rt355.h"
+
 // Relative safety margin of the conservative discriminant filter (see rt_kernels.hip).
 #define RT_FILTER_KAPPA 1.52587890625e-05f   // 2^-16
 // Extra margin of the expanded form used for per-lane ray origins: eps * (|o|^2 + |c|^2).
@@ -80,6 +82,17 @@ struct RtLaunchCfg {
     int mode;      // rt_mode
     int variant;   // kernel variant id; 0 = default
 };
+
+// The kernel form the last rt_launch_* call on this thread chose (rt_kernel_id of include/rt355.h).
+extern thread_local int g_rt_kernel_id;
+
+// Per-frame instance data of a triangle scene, carried in the kernarg block of apply_instances (rt_assemble.hip).
+struct RtInstanceArgs {
+    float* nodes;  float* blas;  float* lookup;          // destinations (one version of each buffer); may be null
+    uint32_t n_head_f, n_blas_f, n_lookup_f;              // floats to write
+    float data[31 * 8 + 16 * 20 + 16];                    // [head | blas | lookup]
+};
+hipError_t rt_launch_apply_instances(const RtInstanceArgs& a, hipStream_t s);
 
 hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);

@@ -174,6 +174,42 @@ class SceneRaytracing:
                    dict(meshIndex=2, position=[0, 0, 0], eulers=[0, 0, 0])]                                # SR:107-111
         return self.createTriangleScene([cat, mousey, flat], records)                                      # SR:71
 
+    # ---- a triangle scene as data: everything a renderer and update(dt) need, without the OBJ files ----
+    def to_packed(self):
+        """dict of arrays: the static upload buffers, the instance records and what the per-frame rebuild reads of
+        each mesh (root node, tree-level box), camera and light.  np.savez-able; from_packed restores the scene."""
+        inst = self.instances
+        return dict(
+            triangles=self.static["triangles"], blas_nodes=self.static["blas_nodes"], tri_lookup=self.static["tri_lookup"],
+            mesh_root=np.array([m.root_node for m in self.meshes], dtype=np.int64),
+            mesh_box_lo=np.array([m.tree.box_lo for m in self.meshes], dtype=np.float64),
+            mesh_box_hi=np.array([m.tree.box_hi for m in self.meshes], dtype=np.float64),
+            inst_mesh=inst.mesh_index, inst_position=inst.position, inst_eulers=inst.eulers, inst_speed=inst.euler_speed,
+            camera_position=np.array(self.camera.position, dtype=np.float64), camera_eulers=np.array(self.camera.eulers, dtype=np.float32),
+            light=np.array(list(self.light.position) + [self.light.lightIntensity, self.light.minIntensity], dtype=np.float64))
+
+    @classmethod
+    def from_packed(cls, d):
+        from types import SimpleNamespace
+        from .instances import Instances
+        s = cls().createScene([])
+        s.camera.position = [float(v) for v in d["camera_position"]]
+        s.camera.eulers = np.asarray(d["camera_eulers"], dtype=np.float32)
+        s.camera.update()
+        lt = [float(v) for v in d["light"]]
+        s.light = Light(position=lt[0:3], lightIntensity=lt[3], minIntensity=lt[4])
+        s.meshes = [SimpleNamespace(root_node=int(r), tree=SimpleNamespace(box_lo=np.asarray(lo), box_hi=np.asarray(hi)))
+                    for r, lo, hi in zip(d["mesh_root"], d["mesh_box_lo"], d["mesh_box_hi"])]
+        s.instances = Instances(d["inst_mesh"], d["inst_position"], d["inst_eulers"], d["inst_speed"])
+        s.static = dict(triangles=np.ascontiguousarray(d["triangles"], dtype=np.float32),
+                        blas_nodes=np.ascontiguousarray(d["blas_nodes"], dtype=np.float32),
+                        tri_lookup=np.ascontiguousarray(d["tri_lookup"], dtype=np.float32))
+        s.triangleCount = s.static["triangles"].shape[0]
+        s.tlasNodesMax = 2 * len(s.instances) - 1
+        s.blasNodesUsed = s.static["blas_nodes"].shape[0]
+        s.buildTopLevel()
+        return s
+
     def buildTopLevel(self):                                   # SR:145-254 into the buffers of RR:169-192
         from .instances import invert_mat4, top_level, world_boxes
         inst = self.instances

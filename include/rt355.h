@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RT355_ABI_VERSION 2
+#define RT355_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -47,8 +47,25 @@ typedef enum rt_status {
     RT_ERR_UNSUPPORTED = -4,  /* combination not supported (e.g. heatmap of a sphere scene) */
     RT_ERR_STATE = -5,        /* call order: e.g. render before resize / write_params   */
     RT_ERR_CAPACITY = -6,     /* destination buffer too small                           */
-    RT_ERR_COMM = -7          /* an RCCL call failed (message has the ncclResult)        */
+    RT_ERR_COMM = -7          /* an RCCL call failed, a peer reported an asynchronous error, or the
+                                 exchange did not complete within rt_set_comm_timeout: the communicator was
+                                 aborted and stays unusable until rt_comm_destroy / rt_group_destroy        */
 } rt_status;
+
+/* Which kernel form rendered a frame (rt_stats.kernel_id): the library chooses by scene type, sphere
+ * count, LDS footprint and mode; callers that price a frame (bench.py) read it from here. */
+typedef enum rt_kernel_id {
+    RT_KID_NONE = 0,
+    RT_KID_LITERAL = 1,          /* trace_pixels, the reference's loop as written (strict mode, or a scene outside the filter's range) */
+    RT_KID_BRUTE_SINGLE = 2,     /* trace_pixels with the FMA filter: one kernel, every sphere tested */
+    RT_KID_BRUTE_PIPELINE = 3,   /* first_bounce + trace_paths over a path queue */
+    RT_KID_HIERARCHY_8 = 4,      /* bvh_pixels, 8-wave workgroups, three per CU, nodes in LDS */
+    RT_KID_HIERARCHY_12 = 5,     /* 12-wave workgroups, two per CU */
+    RT_KID_HIERARCHY_16 = 6,     /* 16-wave workgroups, one per CU */
+    RT_KID_HIERARCHY_GLOBAL = 7, /* nodes read from global memory (scenes beyond a CU's LDS) */
+    RT_KID_TRIANGLES = 8,        /* trace_triangles (TLAS / BLAS traversal) */
+    RT_KID_HEATMAP = 9           /* heatmap_triangles */
+} rt_kernel_id;
 
 typedef enum rt_kernel {
     RT_KERNEL_RAYTRACER = 0,  /* RR:70-72 showRaytracer()  */
@@ -80,6 +97,11 @@ typedef struct rt_stats {
     float gather_ms;              /* rt_render_gather / rt_group_render: RCCL exchange + de-interleave of the
                                      last frame (hipEvents, same stream); kernel_ms then is the render alone */
     float batch_gather_ms;        /* ... summed over the frames the last rt_wait completed   */
+    uint32_t kernel_id;           /* rt_kernel_id of the latest frame enqueued                */
+    uint32_t grid_share;          /* that frame's share of the chip: 1 = all resident slots, k = 1/k of them
+                                     (frames on k distinct streams in flight)                 */
+    uint32_t instance_uploads;    /* frames whose per-frame instance data (rt_write_blas / _blas_lookup /
+                                     _nodes at offset 0) travelled with the frame, without a drain */
 } rt_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------- */
@@ -93,6 +115,12 @@ int rt_destroy(rt_ctx* ctx);
 const char* rt_last_error(rt_ctx* ctx);
 
 int rt_abi_version(void);
+
+/* sha256 (hex, first 16 digits) of the library's sources at build time: profiles taken with one build are
+ * not evidence for another (bench.py matches it against profiles/traffic.json). */
+const char* rt_build_id(void);
+/* Name of a kernel form, e.g. "bvh_pixels<8>" (static storage). */
+const char* rt_kernel_name(int kernel_id);
 
 /* ---- resources ----------------------------------------------------------------------- */
 
@@ -127,6 +155,13 @@ int rt_write_cubemap_face(rt_ctx* ctx, int face, uint32_t w, uint32_t h, const u
  * queue.writeBuffer(nodeBuffer, offset, ...): the TLAS nodes are rewritten every frame at offset
  * 0 (RR:184-192), the BLAS nodes once at 32*tlasNodesMax (RR:212-223).  Writing triangles or
  * nodes switches the context to the triangle scene; rt_write_spheres switches back. */
+/* Per-frame instance data.  The reference rewrites the BLAS records, the BLAS lookup and the TLAS nodes
+ * before EVERY frame (RR:169-192; scene-raytracing.ts:138-143).  Those three writes -- rt_write_blas and
+ * rt_write_blas_lookup of up to 16 instances, rt_write_nodes inside the first 31 nodes -- do not wait for
+ * the frames in flight: the library keeps their current contents on the host, and the next frame carries
+ * them to the device itself (in the kernarg block of a one-workgroup kernel, in front of the ray-trace
+ * kernel on the frame's stream, into one of four versions of the three buffers -- a frame in flight keeps
+ * reading the version it was enqueued with).  Larger instance sets, and every other rt_write_*, drain. */
 int rt_write_triangles(rt_ctx* ctx, const float* data, uint32_t n_triangles);        /* RR:198-209 */
 int rt_write_nodes(rt_ctx* ctx, size_t byte_offset, const float* data, uint32_t n);  /* RR:184-192, 212-223 */
 int rt_write_blas(rt_ctx* ctx, const float* data, uint32_t n_blas);                  /* RR:169-174 */
@@ -213,6 +248,15 @@ int rt_comm_unique_id(uint8_t id[RT355_COMM_ID_BYTES]);
 int rt_comm_init(rt_ctx* ctx, const uint8_t id[RT355_COMM_ID_BYTES], uint32_t rank, uint32_t world);
 int rt_comm_destroy(rt_ctx* ctx);      /* back to a single-GPU context (rank 0 of 1) */
 
+/* Failure of a peer.  rt_wait on a context with a communicator polls its frames' events and, between
+ * polls, ncclCommGetAsyncError; when RCCL reports an error, or when `ms` > 0 and the frames have not
+ * completed within `ms` milliseconds of the rt_wait call, the communicator is aborted (ncclCommAbort:
+ * the exchange kernels leave the device), rt_wait returns RT_ERR_COMM, and every later rt_render_gather /
+ * rt_group_render on it returns RT_ERR_COMM at once.  The context stays valid for rt_comm_destroy,
+ * rt_destroy and single-GPU rendering.  A host that wants to retry forms a new group (in a fresh child
+ * process if the GPU itself is gone).  ms = 0 (default): no deadline, errors only. */
+int rt_set_comm_timeout(rt_ctx* ctx, uint32_t ms);
+
 /* Collective; replaces RendererRaytracing.render()'s submit (RR:442-446, 465) for the whole group:
  * this rank's tiles are rendered, exchanged over RCCL on the same stream and de-interleaved into the
  * row-major W x H frame.  root >= 0: only that rank receives (grouped ncclSend / ncclRecv -- each
@@ -223,7 +267,8 @@ int rt_comm_destroy(rt_ctx* ctx);      /* back to a single-GPU context (rank 0 o
 int rt_render_gather(rt_ctx* ctx, int root);
 
 /* The frame of the latest rt_render_gather on a rank that received it: device address (valid until
- * four more frames are enqueued / rt_resize / rt_destroy), or a copy to host memory (waits first;
+ * four more frames are enqueued / rt_resize / rt_destroy; after rt_resize or rt_set_partition the call
+ * fails with RT_ERR_STATE until the next rt_render_gather), or a copy to host memory (waits first;
  * cap >= W*H*4).  RT_ERR_STATE on a rank that did not receive.  rt_read_pixels / rt_device_pixels
  * keep returning this rank's own tiles. */
 int rt_frame_pixels(rt_ctx* ctx, void** out_ptr, size_t* out_bytes);

@@ -309,6 +309,8 @@ typedef struct {
     char msg[256];
     napi_deferred deferred;
     napi_async_work work;
+    napi_ref keep;           /* strong reference to the context's external: it cannot be collected (and `h` freed)
+                                while the worker thread is inside rt_wait */
 } wait_job;
 
 static void wait_execute(napi_env env, void* data) {
@@ -333,22 +335,36 @@ static void wait_complete(napi_env env, napi_status status, void* data) {
         napi_reject_deferred(env, j->deferred, err);
     }
     napi_delete_async_work(env, j->work);
+    if (j->keep) napi_delete_reference(env, j->keep);
     free(j);
 }
 
 /* wait(ctx) / groupWait(group) -> Promise<void>.  Until it settles every other call on the same context
  * (or on the group and its members) throws: the C context is single-threaded. */
-static napi_value queue_wait(napi_env env, handle* h) {
+static napi_value queue_wait(napi_env env, handle* h, napi_value external) {
     napi_value promise, name;
     wait_job* j = (wait_job*)calloc(1, sizeof *j);
     if (!j) { napi_throw_error(env, NULL, "rt355: out of memory"); return NULL; }
     j->h = h;
-    NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
-    NAPI_OK(napi_create_string_utf8(env, "rt355.wait", NAPI_AUTO_LENGTH, &name));
-    NAPI_OK(napi_create_async_work(env, NULL, name, wait_execute, wait_complete, j, &j->work));
+    if (napi_create_reference(env, external, 1, &j->keep) != napi_ok) {
+        free(j);
+        napi_throw_error(env, NULL, "rt355: cannot reference the context");
+        return NULL;
+    }
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+        napi_create_string_utf8(env, "rt355.wait", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, wait_execute, wait_complete, j, &j->work) != napi_ok) {
+        napi_delete_reference(env, j->keep);
+        free(j);
+        napi_throw_error(env, NULL, "rt355: cannot create the wait job");
+        return NULL;
+    }
     h->busy = 1;
     if (napi_queue_async_work(env, j->work) != napi_ok) {
         h->busy = 0;
+        napi_delete_async_work(env, j->work);
+        napi_delete_reference(env, j->keep);
+        free(j);
         napi_throw_error(env, NULL, "rt355: cannot queue the wait");
         return NULL;
     }
@@ -361,7 +377,7 @@ static napi_value Wait(napi_env env, napi_callback_info info) {
     handle* h = get_handle(env, argv[0], 0);
     if (!h) return NULL;
     if (h->parent) { napi_throw_error(env, "-5", "rt355: wait for a group member through groupWait()"); return NULL; }
-    return queue_wait(env, h);
+    return queue_wait(env, h, argv[0]);
 }
 
 static napi_value WaitSync(napi_env env, napi_callback_info info) {
@@ -411,6 +427,9 @@ static napi_value Stats(napi_env env, napi_callback_info info) {
     set_num(env, obj, "batchKernelMs", st.batch_kernel_ms);
     set_num(env, obj, "gatherMs", st.gather_ms);
     set_num(env, obj, "batchGatherMs", st.batch_gather_ms);
+    set_num(env, obj, "kernelId", st.kernel_id);
+    set_num(env, obj, "gridShare", st.grid_share);
+    set_num(env, obj, "instanceUploads", st.instance_uploads);
     return obj;
 }
 
@@ -488,7 +507,7 @@ static napi_value GroupWait(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
     handle* h = get_handle(env, argv[0], 1);
-    return h ? queue_wait(env, h) : NULL;
+    return h ? queue_wait(env, h, argv[0]) : NULL;
 }
 
 static napi_value GroupWaitSync(napi_env env, napi_callback_info info) {

@@ -114,3 +114,74 @@ def test_incomplete_triangle_scene_is_a_state_error():
         assert L.rt_write_nodes(ctx, 8, t.ctypes.data_as(fp), 1) == abi.RT_ERR_INVALID_ARG
     finally:
         L.rt_destroy(ctx)
+
+
+def test_instance_updates_travel_with_the_frame(oracle):
+    """RR:169-192 rewrites BLAS records, BLAS lookup and TLAS nodes before every frame.  Those writes no longer
+    drain: frames are enqueued back to back (rt_render_to, nothing waited for in between) while the host keeps
+    rewriting the instance data; every frame must show the state it was enqueued with."""
+    import torch
+    scene, mat = triangle_scene(seed=21, n_models=3)
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    W, H, B, N = 200, 120, 3, 7                                       # 7 frames: the four buffer versions wrap
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+    try:
+        r.render()                                                    # static part uploaded, first state applied
+        base = r.stats()["instance_uploads"]
+        bufs = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(N)]
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        torch.cuda.synchronize()
+        refs = []
+        for f in range(N):
+            scene.update(0.21)
+            scene.camera.move(0.05, -0.02)
+            refs.append(oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)[0])
+            r.render_to(bufs[f].data_ptr(), bufs[f].numel(), streams[f % 2].cuda_stream)      # no wait
+        r.wait()
+        torch.cuda.synchronize()
+        st = r.stats()
+        assert st["batch_frames"] == N and st["instance_uploads"] == base + N
+        for f in range(N):
+            img = bufs[f].cpu().numpy().reshape(H, W, 4)
+            assert np.array_equal(img, refs[f]), (f, diff_stats(img, refs[f]))
+        # an unchanged scene: each version is brought up to date once, then nothing travels any more
+        for _ in range(6):
+            r.enqueue()
+        r.wait()
+        assert r.stats()["instance_uploads"] <= base + N + 3
+        assert np.array_equal(r.read_pixels(), refs[-1])
+    finally:
+        r.close()
+
+
+def test_large_instance_sets_and_whole_buffer_node_writes(oracle):
+    """More than 16 instances take the synchronous path; a host that writes the WHOLE node buffer in one call
+    (head included) and later only the head must see both; stats name the kernel."""
+    scene, mat = triangle_scene(seed=23, n_models=19, rings=4, sectors=5)
+    assert len(scene.instances) == 20
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    W, H, B = 160, 96, 2
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+    try:
+        for _ in range(2):
+            scene.update(0.3)
+            r.render()
+            ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
+            assert np.array_equal(r.read_pixels(), ref) and r.stats()["rays"] == rays
+        assert r.stats()["kernel_id"] == 8 and abi.KERNEL_IDS[8] == "triangles"
+    finally:
+        r.close()
+    small, mat = triangle_scene(seed=24, n_models=2)
+    L = abi.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    r = rt.RendererRaytracing(W, H, small, maxBounces=B).initialize(sky, mat)
+    try:
+        r.render()                                                    # reference order of writes
+        whole = np.ascontiguousarray(tri_buffers(small, mat)["nodes"])
+        abi.check(L.rt_write_nodes(r._ctx, 0, whole.ctypes.data_as(fp), whole.shape[0]), r._ctx)   # head + body in one write
+        small.update(0.4)
+        r.render()                                                    # then the per-frame head write again
+        ref, _, _ = oracle.render_tri(small.pack_params(B), tri_buffers(small, mat), sky.faces, W, H)
+        assert np.array_equal(r.read_pixels(), ref)
+    finally:
+        r.close()
