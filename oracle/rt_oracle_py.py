@@ -223,8 +223,9 @@ def tri_counters():
     return int(out[0]), int(out[1]), int(out[2])
 
 
-def trace_tri_rays(buffers, origins, dirs):
-    """Nearest-hit t (or -1) of arbitrary rays against a triangle scene (RK:168-244)."""
+def trace_tri_rays(buffers, origins, dirs, want_tri=False):
+    """Nearest-hit t (or -1) of arbitrary rays against a triangle scene (RK:168-244); want_tri: also the index of
+    the triangle hit (-1: none)."""
     t, keep = _tri_scene(buffers)
     o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
@@ -233,10 +234,12 @@ def trace_tri_rays(buffers, origins, dirs):
     L.rt_oracle_trace_tri_rays.restype = ctypes.c_int
     L.rt_oracle_trace_tri_rays.argtypes = [ctypes.POINTER(_TriScene), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p]
-    rc = L.rt_oracle_trace_tri_rays(ctypes.byref(t), o.shape[0], o.ctypes.data, d.ctypes.data, out.ctypes.data, None)
+    tri = np.full(o.shape[0], -1, dtype=np.int32) if want_tri else None
+    rc = L.rt_oracle_trace_tri_rays(ctypes.byref(t), o.shape[0], o.ctypes.data, d.ctypes.data, out.ctypes.data,
+                                    tri.ctypes.data if want_tri else None)
     if rc != 0:
         raise RuntimeError("rt_oracle_trace_tri_rays failed")
-    return out
+    return (out, tri) if want_tri else out
 
 
 def max_threads():

@@ -61,3 +61,21 @@ def gpu_render_tri(scene, material, width, height, bounces, skybox=None, heatmap
     st = r.stats()
     r.close()
     return img, st
+
+
+# ---- the reference's own scene, as committed fixtures (tests/golden/make_ref_scene.py) ----
+def ref_fixture():
+    """-> (scene, sky CubemapMaterial, W, H, maxBounces, canvas (H,W,3) uint8, pin dict).  Reads only tests/golden/."""
+    import json
+    import os
+    from PIL import Image
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = np.load(os.path.join(g, "ref_scene.npz"))
+    scene = rt.SceneRaytracing.from_packed(d)
+    strip = np.array(Image.open(os.path.join(g, "ref_sky.png")).convert("RGBA"), dtype=np.uint8)
+    sky = rt.CubemapMaterial()
+    n = strip.shape[0]
+    sky.faces = [np.ascontiguousarray(strip[:, k * n:(k + 1) * n]) for k in range(6)]
+    canvas = np.array(Image.open(os.path.join(g, "ref_canvas.png")).convert("RGB"), dtype=np.uint8)
+    pin = json.load(open(os.path.join(g, "ref_pin.json")))
+    return scene, sky, int(d["W"]), int(d["H"]), int(d["maxBounces"]), canvas, pin

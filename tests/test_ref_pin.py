@@ -1,0 +1,115 @@
+"""The oracle against the one output the reference itself holds: info/sample_settings.png, the screenshot of
+its own scene (README.md:3).  tests/golden/make_ref_scene.py rebuilt that scene from the reference's OBJ files
+and sky box, found the scene state the GUI only shows rounded (camera, light x / z, minIntensity, mousey's
+angle) and committed scene, sky, the screenshot's canvas and the agreement figures as fixtures.  Here the
+oracle renders the committed scene again and the figures are re-derived: outside the pixels that depend on
+the one asset the reference does not ship (mousey's diffuse texture) the oracle's frame IS the reference's
+frame -- every pixel of the sky within one level of 255, 99.98 % of all texture-free pixels within one, 95 %
+identical.  The GPU half renders the same scene through the C ABI, bit for bit the oracle's frame."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import compute_raytracer_amd as rt
+from helpers import diff_stats, gpu_render_tri, ref_fixture, tri_buffers
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return ref_fixture()
+
+
+def test_fixture_is_the_reference_scene(ref):
+    scene, sky, W, H, B, canvas, pin = ref
+    assert (W, H, B) == (1344, 846, 4) and canvas.shape == (846, 1344, 3)
+    assert scene.triangleCount == 12604 == pin["triangles"]          # "Primitive count: 12604" in the screenshot's overlay
+    assert len(scene.instances) == 3 and scene.tlasNodesMax == 5
+    assert [f.shape for f in sky.faces] == [(512, 512, 4)] * 6
+    st = pin["state"]
+    # what the GUI displays, rounded to each controller's precision (src/app.ts:89-113; dat.GUI NumberController)
+    assert [round(st["light"][0]), st["light"][1], round(st["light"][2])] == [-2, 5.0, 2]
+    assert round(st["minIntensity"], 2) == 0.3 and st["lightIntensity"] == 3.0
+    assert round(st["mousey_x"], 1) == 0 and round(st["mousey_z"]) == 0 and (st["cat_x"], st["cat_z"]) == (-2.5, 0.0)
+
+
+def test_oracle_frame_is_the_screenshot_outside_the_missing_texture(ref, oracle):
+    import make_ref_scene as m
+    scene, sky, W, H, B, canvas, pin = ref
+    frame, rays, rep = m.evaluate(scene, sky.faces, canvas, oracle)
+    assert hashlib.sha256(frame.tobytes()).hexdigest() == pin["oracle_frame_sha256_white_texture"] and rays == pin["oracle_rays"]
+    assert rep == pin["agreement_levels_of_255_max_over_channels"]              # the committed figures are these
+    # the bar, in levels of 255 (max over the three channels) between the oracle's frame and the reference's canvas
+    assert rep["texture_free_fraction"] > 0.85
+    assert rep["sky"]["within1"] == 1.0 and rep["sky"]["exact"] > 0.95 and rep["sky"]["max"] <= 6
+    assert rep["floor"]["within1"] > 0.9995 and rep["floor"]["exact"] > 0.94
+    assert rep["cat"]["within1"] > 0.995 and rep["cat"]["exact"] > 0.93
+    assert rep["texture_free"]["mean"] < 0.06 and rep["texture_free"]["within2"] > 0.9995
+
+
+def test_wrong_conventions_do_not_survive_the_comparison(ref, oracle):
+    """What the comparison is able to refute: each of these one-line departures from the oracle's reading of the
+    shader leaves the texture-free agreement far below the committed one."""
+    import make_ref_scene as m
+    scene, sky, W, H, B, canvas, pin = ref
+    base = pin["agreement_levels_of_255_max_over_channels"]["sky"]["within1"]
+    white = tri_buffers(scene, rt.Material.white())
+    p = scene.pack_params(B)
+    # pure sky, clear of the overlay and of mousey: the -Z face on the left, the +X face on the right, and the cube
+    # edge between them (it crosses the canvas at x = 804, above mousey's head)
+    windows = [(slice(0, 200), slice(200, 660)), (slice(0, 130), slice(700, 900)), (slice(0, 200), slice(1100, 1340))]
+    cls = m.regions(scene, white, W, H, oracle)
+    assert all((cls[w] == 0).all() for w in windows)
+    def within1(params, faces):
+        img, _, _ = oracle.render_tri(params, white, faces, W, H)
+        if os.environ.get("RT_PIN_VERBOSE"): print([round(float((np.abs(img[w][..., :3].astype(int) - canvas[w].astype(int)).max(-1) <= 1).mean()), 3) for w in windows])
+        return [float((np.abs(img[w][..., :3].astype(int) - canvas[w].astype(int)).max(-1) <= 1).mean()) for w in windows]
+    assert min(within1(p, sky.faces)) == 1.0 == base
+    # the vertical coefficient divided by the HEIGHT instead of the width (RK:79 divides both by the width):
+    # emulated by scaling the up vector by W / H
+    q = p.copy(); q[12:15] *= np.float32(W / H)
+    assert max(within1(q, sky.faces)) < 0.9
+    # cube faces in another order (cubemap-material.ts:40-47): +X and -X swapped, +Z and -Z swapped
+    f = sky.faces
+    assert within1(p, [f[1], f[0], f[2], f[3], f[4], f[5]])[2] < 0.9
+    assert within1(p, [f[0], f[1], f[2], f[3], f[5], f[4]])[0] < 0.9
+    # faces flipped vertically, or mirrored
+    assert max(within1(p, [np.ascontiguousarray(x[::-1]) for x in f])) < 0.9
+    assert min(within1(p, [np.ascontiguousarray(x[:, ::-1]) for x in f])) < 0.9
+    # the sky not scaled by minIntensity (RK:92)
+    r = p.copy(); r[20] = 1.0
+    assert max(within1(r, sky.faces)) < 0.05
+    # minIntensity exactly 0.3 (the displayed value) instead of the fitted 0.29976: the sky's saturated blue then sits on
+    # a rounding tie (255 x 0.3 = 76.5 -> 77 under round-half-up; the canvas shows 76)
+    r = p.copy(); r[20] = np.float32(0.3)
+    assert 0.7 < min(within1(r, sky.faces)) and max(within1(r, sky.faces)) == 1.0
+
+
+@pytest.mark.gpu
+def test_reference_scene_on_the_gpu_bit_exact(ref, oracle):
+    """The scene of the reference's screenshot through rt_write_triangles / _nodes / _blas / _tri_lookup /
+    _blas_lookup and the gfx950 kernel: the oracle's frame, bit for bit, and the oracle's ray count."""
+    scene, sky, W, H, B, canvas, pin = ref
+    img, st = gpu_render_tri(scene, rt.Material.white(), W, H, B, skybox=sky)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == pin["oracle_frame_sha256_white_texture"]
+    assert st["rays"] == pin["oracle_rays"]
+    # and with it the reference's own frame, outside the missing texture
+    d = np.abs(img[..., :3].astype(int) - canvas.astype(int)).max(-1)
+    assert (d[:200, 200:760] <= 1).all()
+    # heatmap twin and a few animation steps of the same scene against the oracle
+    himg, _ = gpu_render_tri(scene, rt.Material.white(), W, H, B, skybox=sky, heatmap=True)
+    href, _ = oracle.heatmap_tri(scene.pack_params(B), tri_buffers(scene, rt.Material.white()), W, H)
+    assert np.array_equal(himg, href)
+    r = rt.RendererRaytracing(W // 2, H // 2, scene, maxBounces=B).initialize(sky, rt.Material.white())
+    try:
+        for _ in range(3):
+            scene.update(0.4)                                              # mousey spins 45 degrees / s (SR:104)
+            r.render()
+            ref_img, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, rt.Material.white()), sky.faces, W // 2, H // 2)
+            assert np.array_equal(r.read_pixels(), ref_img), diff_stats(r.read_pixels(), ref_img)
+            assert r.stats()["rays"] == rays
+    finally:
+        r.close()
