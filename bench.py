@@ -55,7 +55,12 @@ PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 PEAK_L2_GBPS = 34500.0      # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 # The reference's live scene type (triangles behind a two-level BVH, RK:168-410) on a procedural scene of the
 # reference scene's size (12.8 k triangles, 3 instances + floor): the window of the reference's screenshot and 4K
-TRI_CONFIGS = {"TRI": dict(width=1344, height=846, bounces=4), "TRI4K": dict(width=3840, height=2160, bounces=4)}
+TRI_CONFIGS = {"TRI": dict(width=1344, height=846, bounces=4), "TRI4K": dict(width=3840, height=2160, bounces=4),
+               # the reference's OWN scene in the state of its screenshot (cat 428 + mousey 12,174 + floor 2 triangles, the
+               # daylight sky box, 1344x846, 4 bounces: what its overlay reports "6 ms" for), from the
+               # fixtures tests/golden/make_ref_scene.py committed; mousey's texture is missing upstream: white stand-in
+               "REF": dict(width=1344, height=846, bounces=4, fixture=True)}
+FLOP_PER_NODE_TEST = 16     # the walk's conservative sphere test: 8 FMAs (rt_bvh.hip)
 FLIGHT = 4                  # frames the library keeps concurrent (rt_ctx rotates over 4 streams / buffer sets)
 
 
@@ -147,16 +152,11 @@ def cpu_baseline_tri(cfg, scene, mat, sky, target_s, gpu_frame):
     }
 
 
-def kernel_label(mode, variant, N, serial=False):
-    hierarchy = mode == "fast" and (variant == 4 or (variant == 0 and N >= (128 if serial else 72)))    # rt_api.hip: bvh_from
-    queue_pipeline = mode == "fast" and not hierarchy and (variant in (2, 3) or (variant in (0, 4, 5) and N >= 320))
-    if mode == "strict":
-        return "trace_pixels<FILTER=false> (literal loop)", hierarchy, queue_pipeline
-    if hierarchy:
-        return "bvh_pixels (bounding-sphere hierarchy, one persistent kernel per frame)", hierarchy, queue_pipeline
-    if queue_pipeline:
-        return "first_bounce + trace_paths (brute force, one frame's ray-trace launches)", hierarchy, queue_pipeline
-    return "trace_pixels (brute force, single kernel)", hierarchy, queue_pipeline
+def kernel_label(kernel_id):
+    """What the library says it launched (rt_stats.kernel_id -- no copy of its dispatch rules here)."""
+    from compute_raytracer_amd import abi
+    name = abi.load().rt_kernel_name(int(kernel_id)).decode()
+    return name, abi.KERNEL_IDS.get(int(kernel_id), "?").startswith("hierarchy"), abi.KERNEL_IDS.get(int(kernel_id)) == "brute_pipeline"
 
 
 def golden_frame(name):
@@ -206,7 +206,19 @@ def main():
     if not tri and name not in rt.BASELINE_CONFIGS:
         sys.exit("bench.py: unknown config %s" % name)
     mat = None
-    if tri:
+    ref_sky = None
+    if tri and TRI_CONFIGS[name].get("fixture"):
+        import numpy as np
+        from PIL import Image
+        g = os.path.join(ROOT, "tests", "golden")
+        d = np.load(os.path.join(g, "ref_scene.npz"))
+        scene = rt.SceneRaytracing.from_packed(d)
+        mat = rt.Material.white()
+        strip = np.array(Image.open(os.path.join(g, "ref_sky.png")).convert("RGBA"), dtype=np.uint8)
+        ref_sky = rt.CubemapMaterial()
+        ref_sky.faces = [np.ascontiguousarray(strip[:, k * strip.shape[0]:(k + 1) * strip.shape[0]]) for k in range(6)]
+        cfg = dict(TRI_CONFIGS[name], spheres=0, seed=0, skybox=None)
+    elif tri:
         from compute_raytracer_amd.procedural import triangle_scene
         cfg = dict(TRI_CONFIGS[name], spheres=0, seed=21, skybox=None)
         scene, mat = triangle_scene(seed=21, n_models=2, rings=48, sectors=64)     # 12,846 triangles, ~10 s of host build
@@ -220,6 +232,8 @@ def main():
         sky = rt.CubemapMaterial.from_png(png) if os.path.exists(png) else rt.CubemapMaterial.synthetic_daylight()
     else:
         sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    if ref_sky is not None:
+        sky = ref_sky
 
     r = rt.RendererRaytracing(W, H, scene, device=local_rank, maxBounces=B)
     r.initialize(sky, mat)
@@ -279,6 +293,7 @@ def main():
         step(a.serial)
     elapsed, kms, gms, kframes = timed(a.steps, a.serial)
     rays_local = r.stats()["rays"]
+    kid_main = r.stats()["kernel_id"]                 # the form the timed frames ran as
     if a.serial:                      # every rt_wait reports its own batch of one: sample the per-frame times afterwards
         kms = gms = 0.0
         kframes = 0
@@ -306,6 +321,32 @@ def main():
         step(True)
         s_elapsed, _, _, _ = timed(ssteps, True)
         serial_ms = s_elapsed / ssteps * 1e3
+    kid_serial = r.stats()["kernel_id"]
+
+    # what a host that READS every frame gets (render, wait, copy the frame to pageable host memory: the PCIe-inclusive
+    # rate -- never `value`), and, for a triangle scene, what the reference's animation loop costs (scene.update on the
+    # host, the per-frame writes of RR:169-192, render, wait: src/app.ts:117-128)
+    readback_ms = animated_ms = animated_host_ms = None
+    if not multi and ssteps > 0:
+        r.enqueue(); r.wait(); r.read_pixels()
+        t0 = time.perf_counter()
+        for _ in range(ssteps):
+            r.enqueue(); r.wait(); r.read_pixels()
+        readback_ms = (time.perf_counter() - t0) / ssteps * 1e3
+        if tri:
+            pose = scene.instances.eulers.copy()
+            t0 = time.perf_counter()
+            for _ in range(ssteps):
+                scene.update(0.016)
+                r.recalculateScene()
+                r.enqueue(); r.wait()
+            animated_ms = (time.perf_counter() - t0) / ssteps * 1e3
+            t0 = time.perf_counter()
+            for _ in range(ssteps):
+                scene.update(0.016)
+            animated_host_ms = (time.perf_counter() - t0) / ssteps * 1e3
+            scene.instances.eulers = pose              # back to the timed frame's state (the oracle sample below renders it)
+            scene.buildTopLevel()
 
     if multi:
         t = torch.tensor([elapsed, float(rays_local), kms / max(kframes, 1), gms / max(kframes, 1), serial_ms or 0.0],
@@ -329,9 +370,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = rays_frame * a.steps / elapsed / 1e6
-        label, hierarchy, queue_pipeline = kernel_label(a.mode, a.variant, N, a.serial)
-        if tri:
-            label, hierarchy, queue_pipeline = "trace_triangles (TLAS/BLAS traversal, pixel per lane, one 8x8 tile per single-wave workgroup)", False, False
+        label, hierarchy, queue_pipeline = kernel_label(kid_main)
         # launches of consecutive frames overlap on the device (each on a share of the chip): the chip-level
         # rate is work per launch / frame period; one frame at a time: / the launch duration.  The two-kernel
         # brute-force pipeline shares a path queue: its frames are serialised by the library.
@@ -358,7 +397,17 @@ def main():
                     estimated = prof is not None
             except Exception:
                 prof = None
+        # a profile is evidence for the build it was taken with: another build's instruction counts are not reported
+        from compute_raytracer_amd import abi as _abi
+        build_id = _abi.load().rt_build_id().decode()
+        stale = prof is not None and prof.get("build_id") != build_id
+        stale_note = None
+        if stale:
+            stale_note = "profiles/traffic.json[%s] was taken with build %s, this library is build %s: re-run tools/collect_profiles.sh" % (
+                prof_key, prof.get("build_id"), build_id)
+            prof = None
         executed = (prof or {}).get("executed", {})
+        counts = (prof or {}).get("counts")
         valu_serial = executed.get("valu_wave_insts_per_launch")               # PMC pass of one-frame-at-a-time launches
         valu = executed.get("valu_wave_insts_per_launch_in_flight", valu_serial) if overlapping else valu_serial
         if valu is not None and estimated:
@@ -382,9 +431,21 @@ def main():
             if serial_ms is not None and not queue_pipeline:
                 s_ach = valu_serial * FLOP_SLOTS_PER_VALU / (serial_ms * 1e-3) / 1e12
                 roof["serial"] = {"time_ms": serial_ms, "achieved": s_ach, "frac": s_ach / PEAK_FP32_TFLOPS}
+            if counts:
+                # what of the issue slots is the algorithm's own arithmetic: the FMAs of the node / leaf tests of the walk
+                # (8 per test) and the flops of the literal evaluations (25 each, HK:308-311), counted by the counting
+                # builds of the same kernel (tools/count_probe.py); lanes_busy = lane-steps with a live ray / all lane-steps
+                useful_flop = FLOP_PER_NODE_TEST * counts["node_and_leaf_tests"] + FLOP_PER_TEST * counts["literal_tests"]
+                if estimated:
+                    useful_flop /= world
+                u = useful_flop / (roof_ms * 1e-3) / 1e12
+                roof["useful"] = {"achieved": u, "frac": u / PEAK_FP32_TFLOPS, "flop_per_launch": useful_flop,
+                                  "node_and_leaf_tests_per_ray": counts["node_and_leaf_tests"] / max(counts["rays"], 1),
+                                  "literal_tests_per_ray": counts["literal_tests"] / max(counts["rays"], 1),
+                                  "lanes_busy": counts.get("lanes_busy")}
         else:
             roof.update({"achieved": None, "frac": None, "traffic": None,
-                         "basis": "no PMC pass for %s under profiles/: executed-instruction roofline not available" % prof_key})
+                         "basis": stale_note or "no PMC pass for %s under profiles/: executed-instruction roofline not available" % prof_key})
         roof["hbm"] = {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
                        "bytes_per_launch": hbm_bytes}
         alg_tf = flops_alg / (roof_ms * 1e-3) / 1e12
@@ -412,15 +473,32 @@ def main():
             else:
                 roof.update({"achieved": None, "frac": None, "basis": "gather counts come from the cpu_baseline leg (--no-cpu-baseline given)"})
             check = {"sampled_tiles_match_oracle": cpu["gpu_rows_match"]} if cpu is not None else None
+            if cfg.get("fixture") and tri_frame is not None:
+                pin = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_pin.json")))
+                check = dict(check or {}, sha256_matches_oracle_frame=hashlib.sha256(tri_frame.tobytes()).hexdigest() == pin["oracle_frame_sha256_white_texture"],
+                             golden="tests/golden/ref_pin.json (the oracle's frame of this scene; it agrees with the reference's screenshot within one "
+                                    "level of 255 on %.2f %% of the pixels that do not depend on the missing texture)"
+                                    % (100 * pin["agreement_levels_of_255_max_over_channels"]["texture_free"]["within1"]))
         out = {
             "metric": ("Mrays/s at %dx%d, %d triangles, %d bounces" % (W, H, scene.triangleCount, B)) if tri else
                       ("Mrays/s at %dx%d, %d spheres, %d bounces" % (W, H, N, B)),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "frames_per_s": 1e3 / ms_per_step,
+            # what a caller gets, by how it calls: the reference's loop awaits every frame (RR:467) = serial; a host that also
+            # copies every frame out pays the PCIe read-back; `value` / ms_per_step are frames enqueued back to back
             "serial_ms_per_step": serial_ms,
+            "serial_value": (rays_frame / (serial_ms * 1e-3) / 1e6) if serial_ms else None,
+            "readback_ms_per_step": readback_ms,
+            "animated_ms_per_step": animated_ms,
+            "animated_host_scene_update_ms": animated_host_ms if animated_ms is not None else None,
+            "kernel": {"id": int(kid_main), "name": label, "serial_id": int(kid_serial), "build_id": build_id},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("%s: %dx%d, procedural triangle scene of the reference scene's size (%d triangles, %d instances, "
+            "config": {"workload": ("REF: %dx%d, the reference's own scene in the state of its screenshot info/sample_settings.png (cat + mousey + floor: "
+                                    "%d triangles, %d instances, %d nodes), %d bounces, its daylight sky box, white stand-in for the missing mousey texture "
+                                    "(tests/golden/ref_scene.npz); the reference's overlay reports 6 ms per frame for it on an unnamed GPU"
+                                    % (W, H, scene.triangleCount, len(scene.instances), scene.node_buffer_length(), B)) if (tri and cfg.get("fixture")) else
+                                   ("%s: %dx%d, procedural triangle scene of the reference scene's size (%d triangles, %d instances, "
                                     "%d nodes; seed %d), %d bounces, constant sky, reference default camera/light"
                                     % (name, W, H, scene.triangleCount, len(scene.instances), scene.node_buffer_length(), cfg["seed"], B)) if tri else
                                    "%s: %dx%d, %d spheres (seed %d), %d bounces, %s, reference default camera/light"

@@ -48,8 +48,57 @@ def writes_only():          # the four C-ABI writes of recalculateScene (params,
         r.recalculateScene()
     return (time.perf_counter() - t0) / K * 1e3
 
+# the library's share alone: the per-frame buffers of K animation steps are built beforehand, the timed loop only
+# writes them (rt_write_blas / _blas_lookup / _nodes through ctypes) and renders
+import ctypes
+from compute_raytracer_amd import abi
+L, c, fp = abi.load(), r._ctx, ctypes.POINTER(ctypes.c_float)
+states = []
+for _ in range(K):
+    scene.update(0.016)
+    states.append(tuple(np.ascontiguousarray(x, dtype=np.float32).copy() for x in (scene.pack_blas(), scene.pack_blas_lookup(), scene.pack_tlas_nodes())))
+
+def prebuilt(in_flight):
+    t0 = time.perf_counter()
+    for b, bl, na in states:
+        L.rt_write_blas(c, b.ctypes.data_as(fp), b.shape[0])
+        L.rt_write_blas_lookup(c, bl.ctypes.data_as(fp), bl.shape[0])
+        L.rt_write_nodes(c, 0, na.ctypes.data_as(fp), na.shape[0])
+        r.enqueue()
+        if not in_flight:
+            r.wait()
+    r.wait()
+    return (time.perf_counter() - t0) / K * 1e3
+
+def phases(animated):
+    """host time of the three phases of a frame, one frame at a time: writes, rt_render (enqueue), rt_wait"""
+    tw = te = tq = 0.0
+    for b, bl, na in states:
+        t0 = time.perf_counter()
+        if animated:
+            L.rt_write_blas(c, b.ctypes.data_as(fp), b.shape[0])
+            L.rt_write_blas_lookup(c, bl.ctypes.data_as(fp), bl.shape[0])
+            L.rt_write_nodes(c, 0, na.ctypes.data_as(fp), na.shape[0])
+        t1 = time.perf_counter()
+        L.rt_render(c)
+        t2 = time.perf_counter()
+        L.rt_wait(c)
+        t3 = time.perf_counter()
+        tw += t1 - t0; te += t2 - t1; tq += t3 - t2
+    return tuple(round(v / K * 1e3, 4) for v in (tw, te, tq))
+
+def stats_line(tag):
+    st = r.stats()
+    print("  %s: device times of the last frame: instance upload + prep %.4f ms, ray-trace kernel %.4f ms" % (tag, st["prep_ms"], st["kernel_ms"]))
+
 for f in (serial, flight):
     f(False); f(True)
+prebuilt(False); prebuilt(True)
+for name, fl, st in (("one frame at a time", False, serial), ("frames in flight", True, flight)):
+    s0 = min(st(False) for _ in range(5)); a0 = min(prebuilt(fl) for _ in range(5))
+    print("%s, prebuilt instance buffers: static %.3f ms, animated %.3f ms: ratio %.3f" % (name, s0, a0, a0 / s0), flush=True)
+    st(False); stats_line("static"); prebuilt(fl); stats_line("animated")
+print("host ms per frame (writes, rt_render, rt_wait): static", phases(False), "animated", phases(True), phases(False), phases(True))
 host = min(host_only() for _ in range(3))
 wr = min(writes_only() for _ in range(3))
 print("host: scene.update %.3f ms, the per-frame writes (4 ctypes calls, no device work) %.3f ms" % (host, wr))
