@@ -16,7 +16,6 @@
 #include <vector>
 
 #include "rt_bvh_build.h"
-#include "rt_blocks_build.h"
 
 thread_local std::string g_rt_err;
 thread_local int g_rt_kernel_id = 0;
@@ -36,15 +35,13 @@ struct rt_rebuild {
     bool stop = false, pending = false, ready = false;
     std::vector<float> in_records;            // job (latest posted wins)
     uint32_t in_n = 0;
-    std::vector<float> out_rec;               // result: the threaded form ...
+    std::vector<float> out_rec;               // result
     std::vector<uint32_t> out_link;
     uint32_t out_n = 0, out_nodes = 0;
-    RtBlockTree out_blk;                      // ... and the block form (rt_blocks_build.h)
 
     void run() {
         std::vector<float> records, rec;
         std::vector<uint32_t> link;
-        RtBlockTree blk;
         for (;;) {
             uint32_t n;
             {
@@ -56,11 +53,9 @@ struct rt_rebuild {
                 pending = false;
             }
             const uint32_t nodes = rt_bvh_build(records.data(), n, rec, link);
-            rt_blocks_build(records.data(), n, blk);
             std::lock_guard<std::mutex> lk(m);
             out_rec.swap(rec);
             out_link.swap(link);
-            std::swap(out_blk, blk);
             out_n = n;
             out_nodes = nodes;
             ready = true;
@@ -153,9 +148,6 @@ const char* rt_kernel_name(int id) {
         case RT_KID_HIERARCHY_GLOBAL: return "bvh_pixels<global>";
         case RT_KID_TRIANGLES: return "trace_triangles";
         case RT_KID_HEATMAP: return "heatmap_triangles";
-        case RT_KID_BLOCKS_8: return "blk_pixels<8>";
-        case RT_KID_BLOCKS_12: return "blk_pixels<12>";
-        case RT_KID_BLOCKS_16: return "blk_pixels<16>";
         default: return "none";
     }
 }
@@ -224,7 +216,6 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
-    (void)hipFree(c->d_blk_rec); (void)hipFree(c->d_blk_link); (void)hipFree(c->d_blk_sub);
     for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex}) (void)hipFree(b->p);
     for (int v = 0; v < kVersions; ++v)
         for (rt_ctx::DevBuf* b : {&c->d_nodes[v], &c->d_blas[v], &c->d_blas_lookup[v]}) (void)hipFree(b->p);
@@ -624,27 +615,16 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         uint32_t nodes = c->bvh_nodes;
         if (!refit) {
             nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link);
-            rt_blocks_build(c->h_records.data(), c->n, c->h_blk);
             upload_topology = true;
         } else if (c->rebuild) {
             std::lock_guard<std::mutex> lk(c->rebuild->m);
             if (c->rebuild->ready && c->rebuild->out_n == c->n) {
                 c->h_bvh_rec.swap(c->rebuild->out_rec);
                 c->h_bvh_link.swap(c->rebuild->out_link);
-                std::swap(c->h_blk, c->rebuild->out_blk);
                 nodes = c->rebuild->out_nodes;
                 upload_topology = true;
             }
             c->rebuild->ready = false;
-        }
-        if (upload_topology && c->h_blk.n_blocks > c->blk_cap) {
-            (void)hipFree(c->d_blk_rec); (void)hipFree(c->d_blk_link); (void)hipFree(c->d_blk_sub);
-            c->d_blk_rec = nullptr; c->d_blk_link = nullptr; c->d_blk_sub = nullptr; c->blk_cap = 0;
-            const size_t nbk = c->h_blk.n_blocks;
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_blk_rec), nbk * 4u * sizeof(float4)));
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_blk_link), nbk * 4u * sizeof(uint32_t)));
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_blk_sub), nbk * 4u * sizeof(uint32_t)));
-            c->blk_cap = (uint32_t)nbk;
         }
         if (nodes + 1u > c->bvh_cap) {
             (void)hipFree(c->d_bvh_rec); (void)hipFree(c->d_bvh_link);
@@ -702,19 +682,12 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             const size_t nn = (size_t)c->bvh_nodes + 1u;
             RT_HIP(hipMemcpyAsync(c->d_bvh_rec, c->h_bvh_rec.data(), nn * sizeof(float4), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemcpyAsync(c->d_bvh_link, c->h_bvh_link.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            const size_t ne = (size_t)c->h_blk.n_blocks * 4u;
-            RT_HIP(hipMemcpyAsync(c->d_blk_rec, c->h_blk.rec.data(), ne * sizeof(float4), hipMemcpyHostToDevice, s));
-            RT_HIP(hipMemcpyAsync(c->d_blk_link, c->h_blk.link.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            RT_HIP(hipMemcpyAsync(c->d_blk_sub, c->h_blk.sub_end.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, s));
             RT_HIP(hipStreamSynchronize(s));   // pageable sources: the vectors may be rebuilt later
             c->bvh_topo_n = c->n;
-            c->blk_blocks = c->h_blk.n_blocks; c->blk_first = c->h_blk.first; c->blk_then = c->h_blk.then;
         }
         // bounds of the inner nodes for the current positions (a topology from the worker was built for older ones)
         if (refit) RT_HIP(rt_launch_bvh_refit(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, c->d_records, s));
         RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, fa.geo_f, s));
-        if (refit) RT_HIP(rt_launch_blocks_refit(c->d_blk_rec, c->d_blk_link, c->d_blk_sub, c->blk_blocks, c->d_records, s));
-        RT_HIP(rt_launch_blocks_fill(c->d_blk_rec, c->d_blk_link, c->blk_blocks, fa.geo_f, s));
         c->bvh_valid = true;
     }
     if (need_prep || need_bvh) {
@@ -724,12 +697,6 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     fa.bvh_rec = use_bvh ? c->d_bvh_rec : nullptr;
     fa.bvh_link = use_bvh ? c->d_bvh_link : nullptr;
     fa.bvh_nodes = use_bvh ? c->bvh_nodes : 0u;
-    // variant 4 keeps the threaded walk (one node per step); the default walks the block form whenever it fits a CU's LDS
-    const bool use_blocks = use_bvh && c->variant != 4 && c->blk_blocks > 1u && c->n < (1u << 16);
-    fa.blk_rec = use_blocks ? c->d_blk_rec : nullptr;
-    fa.blk_link = use_blocks ? c->d_blk_link : nullptr;
-    fa.blk_blocks = use_blocks ? c->blk_blocks : 0u;
-    fa.blk_first = c->blk_first; fa.blk_then = c->blk_then;
     // frames in flight on DIFFERENT streams run concurrently and share the chip: this frame's grid is
     // 1 / (number of distinct streams among it and the kStreams-1 frames enqueued before it)
     c->slot_stream[slot] = s;
@@ -810,10 +777,8 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
     } else {
-        bool taken = false;
-        if (use_blocks) RT_HIP(rt_launch_blocks(fa, s, &taken));
-        if (use_bvh && !taken) RT_HIP(rt_launch_bvh(fa, s));
-        if (!use_bvh) RT_HIP(rt_launch_trace(fa, cfg, s));
+        if (use_bvh) RT_HIP(rt_launch_bvh(fa, s));
+        else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
     c->stats.kernel_id = (uint32_t)g_rt_kernel_id;

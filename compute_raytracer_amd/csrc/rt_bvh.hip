@@ -714,12 +714,6 @@ extern "C" __attribute__((visibility("default"))) int rt_debug_wave_clock(unsign
 }
 #endif
 
-hipError_t rt_launch_sky_resolve(const RtFrameArgs& a, hipStream_t s) {      // also behind rt_blocks.hip's kernel
-    const uint32_t slots = a.n_local_tiles * 8u * a.W;
-    hipLaunchKernelGGL(rtk::sky_resolve, dim3(std::min((slots + 255u) / 256u, 256u * 8u)), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
 hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     return a.signed_filter ? rtk::launch_bvh<true>(a, s) : rtk::launch_bvh<false>(a, s);
 }

@@ -9,8 +9,6 @@
 #include <string>
 #include <vector>
 
-#include "rt_blocks_build.h"
-
 extern thread_local std::string g_rt_err;      // rt_last_error()
 
 inline int fail(int code, const char* what) {
@@ -77,12 +75,6 @@ struct rt_ctx {
     float4* d_bvh_rec = nullptr;
     uint32_t* d_bvh_link = nullptr;
     uint32_t bvh_cap = 0, bvh_nodes = 0;
-    // ... and its block form (rt_blocks_build.h, rt_blocks.hip): built, refitted and kept current together with the threaded one
-    RtBlockTree h_blk;
-    float4* d_blk_rec = nullptr;
-    uint32_t* d_blk_link = nullptr;
-    uint32_t* d_blk_sub = nullptr;
-    uint32_t blk_cap = 0, blk_blocks = 0, blk_first = 0, blk_then = 0;
     bool bvh_valid = false;              // the device records bound the current spheres
     uint32_t bvh_topo_n = 0;             // sphere count the device topology (links, leaf ids) was built for; 0: none
     struct rt_rebuild* rebuild = nullptr;   // worker thread that rebuilds the topology for moved spheres (rt_api.hip)

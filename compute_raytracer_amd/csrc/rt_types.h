@@ -65,12 +65,6 @@ struct RtFrameArgs {
     const float4* bvh_rec;     // [bvh_nodes] node records, same layout as geo_f (leaves ARE geo_f records)
     const uint32_t* bvh_link;  // [bvh_nodes] inner node: 4 * (index after its subtree); leaf: 0x80000000 | sphere
     uint32_t bvh_nodes;        // 0: no hierarchy built
-    // the same hierarchy in BLOCK form (rt_blocks.hip; rt_blocks_build.h): 4 records + 4 links per block
-    const float4* blk_rec;     // [4 * blk_blocks]
-    const uint32_t* blk_link;  // [4 * blk_blocks]  leaf block: 0x80000000 | sphere; inner block: child block; unused: 0xFFFFFFFF
-    uint32_t blk_blocks;       // 0: no block hierarchy
-    uint32_t blk_first;        // where a ray starts, and (blk_then != 0) the block it visits after that one's subtree
-    uint32_t blk_then;
     uint32_t grid_share;       // >1: this frame's persistent grid takes 1/grid_share of the chip (frames in flight)
     uint32_t bvh_tail;         // lanes still walking below which a wave leaves the walk for the shading pass (0: never)
 };
@@ -103,10 +97,6 @@ hipError_t rt_launch_apply_instances(const RtInstanceArgs& a, hipStream_t s);
 hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
 hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s);
-hipError_t rt_launch_sky_resolve(const RtFrameArgs& a, hipStream_t s);
-hipError_t rt_launch_blocks(const RtFrameArgs& a, hipStream_t s, bool* taken);      // *taken = false: the scene does not fit a CU's LDS in block form
-hipError_t rt_launch_blocks_refit(float4* rec, const uint32_t* link, const uint32_t* sub_end, uint32_t n_blocks, const float* records, hipStream_t s);
-hipError_t rt_launch_blocks_fill(float4* rec, const uint32_t* link, uint32_t n_blocks, const float4* geo_f, hipStream_t s);
 hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, hipStream_t s);
 hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t W, uint32_t H,

@@ -64,10 +64,7 @@ typedef enum rt_kernel_id {
     RT_KID_HIERARCHY_16 = 6,     /* 16-wave workgroups, one per CU */
     RT_KID_HIERARCHY_GLOBAL = 7, /* nodes read from global memory (scenes beyond a CU's LDS) */
     RT_KID_TRIANGLES = 8,        /* trace_triangles (TLAS / BLAS traversal) */
-    RT_KID_HEATMAP = 9,          /* heatmap_triangles */
-    RT_KID_BLOCKS_8 = 10,        /* blk_pixels: the hierarchy walked four children per step (rt_blocks.hip), 8-wave workgroups */
-    RT_KID_BLOCKS_12 = 11,       /* ... 12-wave workgroups, two per CU */
-    RT_KID_BLOCKS_16 = 12        /* ... 16-wave workgroups, one per CU */
+    RT_KID_HEATMAP = 9           /* heatmap_triangles */
 } rt_kernel_id;
 
 typedef enum rt_kernel {
