@@ -73,9 +73,6 @@
 #ifndef RT_BVH_TAIL_SERIAL
 #define RT_BVH_TAIL_SERIAL 12  /* ... when one frame has the chip to itself */
 #endif
-#ifndef RT_BVH_COOP
-#define RT_BVH_COOP 6u         /* rays left in a wave, after the cursor has run dry, from which the wave scans for them together (coop_scan) */
-#endif
 #ifndef RT_BVH_TAIL_LARGE
 #define RT_BVH_TAIL_LARGE 32   /* 16-wave workgroups and the global-memory form */
 #endif
@@ -384,82 +381,6 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
     i = (j - l0) >> 2;
 }
 
-// ---- the end of a frame: a wave's last rays, traced by the whole wave --------------------------------------------
-// When the frame's pixel cursor has run dry a wave refills no more: its lanes finish their paths and go idle, and the
-// wave lives as long as its longest path -- up to 2 x maxBounces rays, each a chain of ~46 dependent walk steps that
-// costs the same ~20 us whether 64 lanes walk or one.  That tail is most of what one frame at a time pays over frames
-// in flight (0.39 ms after the cursor runs dry at C3; two thirds of a rank-of-eight's frame).
-// Once few of a wave's lanes still have a ray (`todo`), the walk is dropped for them: each of those rays in turn is
-// handed to ALL 64 lanes, which test every leaf of the hierarchy against it -- lane l the nodes l, l + 64, ... --
-// with the walk's own conservative leaf test and the reference's literal arithmetic for what passes, and fold their
-// hits into the owner's slot with the pooled evaluation's 64-bit LDS atomicMin.  n / 64 independent steps with
-// consecutive (conflict-free) LDS addresses instead of a dependent chain: ~1 us per ray.  A scan of every sphere finds
-// what the walk finds -- the lexicographic minimum of (t, index) over all spheres the literal test accepts --, so a
-// suspended walk's partial result is simply superseded.  Only with the nodes in LDS (NLDS).
-template <bool SGN>
-__device__ __forceinline__ void coop_scan(uint64_t todo, const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
-                                          const float4* __restrict__ geo, unsigned long long* best, v3 o, v3 d,
-                                          uint32_t& node, float& nearest, int& idx) {
-    const uint32_t lane = threadIdx.x & 63u;
-    best[lane] = ((unsigned long long)__float_as_uint(9999.0f) << 32) | 0xFFFFFFFFull;      // RK:172
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (uint64_t m = todo; m != 0ull; m &= m - 1ull) {
-        const int owner = (int)__builtin_ctzll(m);
-        const v3 oo = V(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
-        const v3 od = V(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
-        // the walk's per-ray quantities (trace_bvh), for the owner's ray
-        const float a = dot(od, od);         // HK:308
-        const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_BVH_KAPPA);
-        const v3 h = V(od.x * inv, od.y * inv, od.z * inv);
-        const v3 os = V(oo.x * RT_FILTER_SCALE, oo.y * RT_FILTER_SCALE, oo.z * RT_FILTER_SCALE);
-        const v3 mm = V(-2.0f * os.x, -2.0f * os.y, -2.0f * os.z);
-        const float p = dot(h, os);
-        const float q = dot(os, os) * (1.0f - RT_FILTER_EPS);
-        constexpr float kT = 2.168404344971009e-19f;            // 2^-62
-        constexpr float kT2 = 4.70197740328915e-38f;            // 2^-124
-        const v3 hs = V(h.x * kT, h.y * kT, h.z * kT);
-        const v3 ms = V(mm.x * kT2, mm.y * kT2, mm.z * kT2);
-        const float ps = -p * kT, qs = q * kT2;
-        for (uint32_t j = lane; j < n; j += 64u) {
-            const uint32_t lk = L[j];
-            if ((int)lk >= 0) continue;                       // an inner node: its leaves are scanned anyway
-            const float4 g = R[j];
-            bool pass;
-            if (SGN) {                                        // the staged records carry w * 2^-124 (the kernel's staging loop)
-                float nb;
-                const float part = fma_vvv(hs.y, g.y, fma_vvv(hs.x, g.x, ps));
-                asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nb) : "v"(hs.z), "v"(g.z), "v"(part));
-                const float cp = fma_vvv(ms.z, g.z, fma_vvv(ms.y, g.y, fma_vvv(ms.x, g.x, g.w)));
-                pass = __builtin_fmaf(nb, nb, -qs) > cp;
-            } else {
-                const float b = fnma_vvv(h.z, g.z, fnma_vvv(h.y, g.y, fnma_vvv(h.x, g.x, p)));
-                const float cp = fma_vvv(mm.z, g.z, fma_vvv(mm.y, g.y, fma_vvv(mm.x, g.x, g.w)));
-                pass = __builtin_fmaf(b, b, -q) > cp;
-            }
-            if (pass) {
-                const int si = (int)(lk & 0x7FFFFFFFu);
-                const float4 e = geo[si];
-                const v3 oc = sub(oo, V(e.x, e.y, e.z));
-                const float b = 2.0f * dot(od, oc);               // HK:309
-                const float c = dot(oc, oc) - e.w;                // HK:310
-                const float disc = b * b - (4.0f * a) * c;        // HK:311
-                if (disc > 0.0f && b < 0.0f) {                    // HK:316; b >= 0 gives t <= 0
-                    const float t = (-b - sqrtf(disc)) / (2.0f * a);   // HK:317
-                    if (t > 0.001f && t < 9999.0f)                // HK:318 with tMin / the initial tMax of RK:315, RK:172
-                        atomicMin(&best[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)si);
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if ((todo >> lane) & 1ull) {
-        const unsigned long long r = best[lane];
-        nearest = __uint_as_float((uint32_t)(r >> 32));
-        idx = (int)(uint32_t)r;
-        node = n;                                             // this lane's ray is complete
-    }
-}
-
 // ---- kernel ---------------------------------------------------------------------------------------------
 // Do `k` workgroups with `bytes` of LDS each fit one CU?  The 160 KB are handed out in 128 granules of 1280 bytes and a
 // workgroup's allocation is rounded up to whole granules -- hipOccupancyMaxActiveBlocksPerMultiprocessor divides the
@@ -601,11 +522,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
         bool finished = active && sc.bounces == 0u;
         bool missed = false;
         const bool walking = node != n;
-        if (NLDS && exhausted && A.bvh_coop != 0u) {             // the frame's end: few rays left in this wave (coop_scan)
-            const uint64_t todo = __ballot(walking);
-            if (todo != 0ull && (uint32_t)__popcll(todo) <= A.bvh_coop)
-                coop_scan<SGN>(todo, R, L, n, A.geo, best, shadow ? sc.lightPos : ro, shadow ? sdir : rd, node, t, idx);
-        }
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
         trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
@@ -724,10 +640,8 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     // small shares (a rank of eight of a 4K frame: 1 M pixels) end sooner after they begin: 12 / 16 / 20 / 24 lanes =
     // 0.298 / 0.300 / 0.302 / 0.307 ms per frame in flight (profiles/r02/knobs_w8.log)
     else if (TAIL == RT_BVH_TAIL_SMALL && a.n_local_tiles * 8u * a.W < (1u << 22)) a.bvh_tail = 16u;
-    a.bvh_coop = NLDS ? RT_BVH_COOP : 0u;
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_TAIL")) a.bvh_tail = (uint32_t)atoi(e);
-    if (const char* e = getenv("RT355_BVH_COOP")) a.bvh_coop = NLDS ? (uint32_t)atoi(e) : 0u;
 #endif
     auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, true> : bvh_pixels<WAVES, SGN, NLDS, CAP, false>;
     if (lds > 48u * 1024u) {

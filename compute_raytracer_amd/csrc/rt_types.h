@@ -67,7 +67,6 @@ struct RtFrameArgs {
     uint32_t bvh_nodes;        // 0: no hierarchy built
     uint32_t grid_share;       // >1: this frame's persistent grid takes 1/grid_share of the chip (frames in flight)
     uint32_t bvh_tail;         // lanes still walking below which a wave leaves the walk for the shading pass (0: never)
-    uint32_t bvh_coop;         // after the pixel cursor has run dry: rays left in a wave from which all 64 lanes scan for them (0: never)
 };
 
 struct RtPrepArgs {
