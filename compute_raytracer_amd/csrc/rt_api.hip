@@ -216,7 +216,7 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
-    for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex}) (void)hipFree(b->p);
+    for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex, &c->d_corners}) (void)hipFree(b->p);
     for (int v = 0; v < kVersions; ++v)
         for (rt_ctx::DevBuf* b : {&c->d_nodes[v], &c->d_blas[v], &c->d_blas_lookup[v]}) (void)hipFree(b->p);
     (void)hipFree(c->d_rays);
@@ -435,6 +435,7 @@ static int write_buf(rt_ctx* c, rt_ctx::DevBuf& b, size_t byte_offset, const voi
 int rt_write_triangles(rt_ctx* c, const float* data, uint32_t n) {                    // RR:198-209
     if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_triangles: NULL argument");
     c->d_tri.used = 0;
+    c->corners_valid = false;
     int rc = write_buf(c, c->d_tri, 0, data, (size_t)n * 160u, "rt_write_triangles: NULL data");
     if (rc == RT_OK) c->scene_kind = 1;
     return rc;
@@ -500,6 +501,7 @@ int rt_write_blas(rt_ctx* c, const float* data, uint32_t n) {                   
 int rt_write_tri_lookup(rt_ctx* c, const float* data, uint32_t n) {                   // RR:225-229
     if (!c || (n && !data)) return fail(RT_ERR_INVALID_ARG, "rt_write_tri_lookup: NULL argument");
     c->d_tri_lookup.used = 0;
+    c->corners_valid = false;
     return write_buf(c, c->d_tri_lookup, 0, data, (size_t)n * 4u, "rt_write_tri_lookup: NULL data");
 }
 int rt_write_blas_lookup(rt_ctx* c, const float* data, uint32_t n) {                  // RR:177-181
@@ -759,6 +761,17 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         c->ver_gen[v] = c->inst.gen;
         ++c->stats.instance_uploads;
     }
+    if (tri && !c->corners_valid) {
+        // the compact corner array follows the triangles and the lookup table; both writes drained, nothing reads it now
+        const uint32_t n_slots = (uint32_t)(c->d_tri_lookup.used / 4u);
+        { int rc = grow_buf(c, c->d_corners, (size_t)n_slots * 48u); if (rc != RT_OK) return rc; }
+        for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[i], 0));
+        RT_HIP(rt_launch_tri_corners(static_cast<float4*>(c->d_corners.p), static_cast<const float*>(c->d_tri.p),
+                                     static_cast<const float*>(c->d_tri_lookup.p), n_slots, (uint32_t)(c->d_tri.used / 160u), s));
+        RT_HIP(hipEventRecord(c->ev_scene, s));          // frames on other streams wait for it (the scene-update event)
+        c->scene_stream = s;
+        c->corners_valid = true;
+    }
     RT_HIP(hipEventRecord(c->ev_k0[slot], s));
     g_rt_kernel_id = RT_KID_NONE;
     if (tri) {
@@ -766,6 +779,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.nodes = static_cast<const float4*>(c->d_nodes[v].p);
         ts.blas = static_cast<const float*>(c->d_blas[v].p);
         ts.tri = static_cast<const float*>(c->d_tri.p);
+        ts.corners = static_cast<const float4*>(c->d_corners.p);
         ts.tri_lookup = static_cast<const float*>(c->d_tri_lookup.p);
         ts.blas_lookup = static_cast<const float*>(c->d_blas_lookup[v].p);
         ts.tex = static_cast<const uint8_t*>(c->d_tex.p);

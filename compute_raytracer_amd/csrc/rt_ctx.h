@@ -95,6 +95,8 @@ struct rt_ctx {
     // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
     struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };
     DevBuf d_tri, d_tri_lookup, d_tex;
+    DevBuf d_corners;                            // 48 B per lookup slot: the corners hitTriangle reads, in lookup order (tri_corners)
+    bool corners_valid = false;                  // ... built since the last rt_write_triangles / rt_write_tri_lookup
     // The buffers the reference rewrites before every frame (RR:169-192: BLAS records, BLAS lookup, the TLAS nodes at
     // the head of the node buffer) exist in kVersions versions: a frame in flight keeps reading the version it was
     // enqueued with while the host already writes the next state (rt_api.hip: apply_instances).

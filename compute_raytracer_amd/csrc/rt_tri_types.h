@@ -6,6 +6,7 @@ struct RtTriScene {
     const float4* nodes;       // [n_nodes][2]  {min.xyz, leftChildIndex}, {max.xyz, primitiveCount}
     const float* blas;         // [n_blas][20]  inverseModel (column-major), rootNodeIndex, pad
     const float* tri;          // [n_tri][40]   RR:198-209
+    const float4* corners;     // [n_tri_lookup][3]  the library's own: cornerA/B/C of triangles[u32(tri_lookup[slot])] (rt_triangles.hip: tri_corners)
     const float* tri_lookup;   // [n_tri_lookup] f32 indices
     const float* blas_lookup;  // [n_blas_lookup] f32 indices
     const uint8_t* tex;        // meshTex, rgba8unorm
@@ -13,3 +14,4 @@ struct RtTriScene {
 };
 
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);
+hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* lookup, uint32_t n_slots, uint32_t n_tri, hipStream_t s);

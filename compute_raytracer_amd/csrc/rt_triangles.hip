@@ -84,14 +84,21 @@ __device__ __forceinline__ v3 cross3(v3 a, v3 b) {
 
 struct TriHit {       // what survives of RenderState during traversal
     float t, u, v;
-    int tri, blas;    // tri < 0: no hit
+    int tri, blas;    // tri: slot of the triangle lookup table (tri_of resolves it), < 0: no hit
 };
+// RK:314 for the accepted hit: the triangle a lookup slot names (u32() of the f32 index, clamped like every index)
+__device__ __forceinline__ uint32_t tri_of(const RtTriScene& T, int slot) {
+    uint32_t ti = u32f(T.tri_lookup[slot]);
+    return ti >= T.n_tri ? T.n_tri - 1u : ti;
+}
 
-// RK:344-381, up to the acceptance test; normal / uv / colour are formed later for the winner
-__device__ __forceinline__ bool hit_triangle(const RtTriScene& T, uint32_t ti, v3 o, v3 d, float tMax,
+// RK:344-381, up to the acceptance test; normal / uv / colour are formed later for the winner.
+// `slot` is the position in the triangle lookup table (RK:314: triangles[u32(triangleLookup[i + left])]); the three
+// corners of that triangle come from T.corners, the library's own compact copy in lookup order (rt_tri_corners below).
+__device__ __forceinline__ bool hit_triangle(const RtTriScene& T, uint32_t slot, v3 o, v3 d, float tMax,
                                              float& t_out, float& u_out, float& v_out) {
-    const float4* tr = reinterpret_cast<const float4*>(T.tri + 40u * (size_t)ti);
-    const float4 A = tr[0], B = tr[3], C = tr[6];                   // corner k at float 12k
+    const float4* tr = T.corners + 3u * (size_t)slot;
+    const float4 A = tr[0], B = tr[1], C = tr[2];
     const v3 cornerA = V(A.x, A.y, A.z);
     const v3 edge1 = sub(V(B.x, B.y, B.z), cornerA);                // RK:354
     const v3 edge2 = sub(V(C.x, C.y, C.z), cornerA);                // RK:355
@@ -166,14 +173,12 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
         } else {
             for (uint32_t i = 0; i < count; ++i) {                  // RK:311
                 uint32_t li = i + left;
-                if (li >= T.n_tri_lookup) li = T.n_tri_lookup - 1u;
-                uint32_t ti = u32f(T.tri_lookup[li]);               // RK:314
-                if (ti >= T.n_tri) ti = T.n_tri - 1u;
+                if (li >= T.n_tri_lookup) li = T.n_tri_lookup - 1u;  // RK:314: the lookup itself is folded into T.corners
                 if (COUNT) traces += 1.0f;                          // HK:279
                 float t, u, v;
-                if (hit_triangle(T, ti, oo, od, blasNearest, t, u, v)) {   // RK:312-321
+                if (hit_triangle(T, li, oo, od, blasNearest, t, u, v)) {   // RK:312-321
                     blasNearest = t;
-                    hit.t = t; hit.u = u; hit.v = v; hit.tri = (int)ti; hit.blas = (int)bi;
+                    hit.t = t; hit.u = u; hit.v = v; hit.tri = (int)li; hit.blas = (int)bi;
                 }
             }
             if (sp == 0u) break;                                    // RK:324
@@ -237,7 +242,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
 // only the normal (which the reflection needs) is carried across the shadow ray's traversal; texture
 // coordinate and colour are read when the bounce is shaded.
 __device__ __forceinline__ v3 hit_normal(const RtTriScene& T, const TriHit& h) {
-    const float* tr = T.tri + 40u * (size_t)h.tri;
+    const float* tr = T.tri + 40u * (size_t)tri_of(T, h.tri);
     const float w = 1.0f - h.u - h.v;                                                // RK:381
     const v3 nA = V(tr[4], tr[5], tr[6]), nB = V(tr[16], tr[17], tr[18]), nC = V(tr[28], tr[29], tr[30]);
     const v3 n = add(add(scale(w, nA), scale(h.u, nB)), scale(h.v, nC));             // RK:382
@@ -248,8 +253,8 @@ __device__ __forceinline__ v3 hit_normal(const RtTriScene& T, const TriHit& h) {
     return normalize(tn);
 }
 struct Albedo { float u, v; v3 rgb; float w; };
-__device__ __forceinline__ Albedo hit_albedo(const RtTriScene& T, int tri, float hu, float hv) {
-    const float* tr = T.tri + 40u * (size_t)tri;
+__device__ __forceinline__ Albedo hit_albedo(const RtTriScene& T, int slot, float hu, float hv) {
+    const float* tr = T.tri + 40u * (size_t)tri_of(T, slot);
     const float w = 1.0f - hu - hv;                                                  // RK:381
     Albedo s;
     s.u = (tr[8] * w + tr[20] * hu) + tr[32] * hv;                                   // RK:386
@@ -365,7 +370,29 @@ __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArg
     count_rays(A.rays, 1u);
 }
 
+// The corners hitTriangle reads (48 of a triangle's 160 bytes), gathered once into lookup order: entry `slot` holds
+// cornerA / B / C of triangles[u32(triangleLookup[slot])] -- the same twelve numbers RK:354-364 reads, so every
+// intersection is bit for bit the reference's --, a leaf's triangles sit side by side, and the traversal touches
+// neither the lookup table nor the 160-byte records until a hit is shaded.
+__global__ void tri_corners(float4* __restrict__ out, const float* __restrict__ tri, const float* __restrict__ lookup,
+                            uint32_t n_slots, uint32_t n_tri) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    uint32_t ti = u32f(lookup[slot]);
+    if (ti >= n_tri) ti = n_tri - 1u;
+    const float4* tr = reinterpret_cast<const float4*>(tri + 40u * (size_t)ti);
+    out[3u * (size_t)slot] = tr[0];
+    out[3u * (size_t)slot + 1u] = tr[3];
+    out[3u * (size_t)slot + 2u] = tr[6];
+}
+
 }  // namespace rtk
+
+hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* lookup, uint32_t n_slots, uint32_t n_tri, hipStream_t s) {
+    if (n_slots == 0 || n_tri == 0) return hipSuccess;
+    hipLaunchKernelGGL(rtk::tri_corners, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, out, tri, lookup, n_slots, n_tri);
+    return hipGetLastError();
+}
 
 // OCC: waves per SIMD the register allocation is held to.  16-bit stacks leave LDS room for four workgroups per
 // CU, and 128 VGPRs (one spilled dword) for the fourth wave per SIMD pay: 4K 0.92 -> 0.79 ms per frame with
