@@ -31,6 +31,16 @@ for m in pipelined serial; do
   cp $OUT/${KEY}__${m}_bench.json $OUT/collected/
 done
 ls -la $OUT/collected $OUT/collected/pmc
+# memory side of the triangle kernel (RT_CACHE_PASSES=1): L1 -> L2 read requests and their latency, L2 hits / misses
+if [ -n "$RT_CACHE_PASSES" ]; then
+  rocprofv3 --output-format csv --pmc TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE -d $OUT/pmc_tcp -o tcp -- python3 bench.py $ARGS --serial > $OUT/pmc_tcp.json 2> $OUT/pmc_tcp.err
+  rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum GRBM_GUI_ACTIVE -d $OUT/pmc_tcc -o tcc -- python3 bench.py $ARGS --serial > $OUT/pmc_tcc.json 2> $OUT/pmc_tcc.err
+  rocprofv3 --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $OUT/pmc_stall -o stall -- python3 bench.py $ARGS --serial > $OUT/pmc_stall.json 2> $OUT/pmc_stall.err
+  for p in tcp tcc stall; do
+    f=$(find $OUT/pmc_$p -name "*counter_collection.csv" | head -n 1)
+    [ -n "$f" ] && cp "$f" $OUT/collected/pmc/${KEY}__$p.csv
+  done
+fi
 # development passes (not needed by bench.py): where the idle issue slots go
 if [ -n "$RT_EXTRA_PASSES" ]; then
   rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o lds -- python3 bench.py $ARGS --serial > $OUT/pmc_lds.json 2> $OUT/pmc_lds.err

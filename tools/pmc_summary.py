@@ -94,6 +94,28 @@ def summarise(files):
         if fl and "SQ_INSTS_VALU" in fl:        # the launches of frames in flight (collect_profiles.sh)
             ex["valu_wave_insts_per_launch_in_flight"] = fl["SQ_INSTS_VALU"]
         entry["executed"] = ex
+    # memory side (collect_profiles.sh RT_CACHE_PASSES): L1 -> L2 read requests (64 B each), their mean latency in
+    # shader cycles, cycles the L1 stalled on pending misses, L2 hit rate
+    cache = {}
+    for name, pv in passes.items():
+        r = pv.get(dom, {})
+        for src, dst in (("TCP_TCC_READ_REQ_sum", "l1_to_l2_read_requests_per_launch"), ("TCP_PENDING_STALL_CYCLES_sum", "l1_pending_stall_cycles_per_launch"),
+                         ("TCP_TCC_READ_REQ_LATENCY_sum", "l1_to_l2_read_latency_cycles_sum_per_launch"), ("TA_FLAT_READ_WAVEFRONTS_sum", "flat_read_wave_instructions_per_launch"),
+                         ("TCC_HIT_sum", "l2_hits_per_launch"), ("TCC_MISS_sum", "l2_misses_per_launch"), ("TCC_REQ_sum", "l2_requests_per_launch"),
+                         ("TCC_READ_sum", "l2_reads_per_launch"), ("SQ_INSTS_VMEM_RD", "vmem_read_wave_insts_per_launch"),
+                         ("SQ_WAIT_ANY", "wait_any_per_launch"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_per_launch")):
+            if src in r:
+                cache[dst] = r[src]
+        if "TCP_TCC_READ_REQ_sum" in r:
+            cache["kernel_ns_of_that_pass"] = r["ns"]
+    if "l1_to_l2_read_requests_per_launch" in cache:
+        cache["l2_read_bytes_per_launch"] = 64.0 * cache["l1_to_l2_read_requests_per_launch"]
+        if cache.get("l1_to_l2_read_latency_cycles_sum_per_launch"):
+            cache["mean_l2_read_latency_cycles"] = cache["l1_to_l2_read_latency_cycles_sum_per_launch"] / cache["l1_to_l2_read_requests_per_launch"]
+    if cache.get("l2_hits_per_launch") is not None and cache.get("l2_misses_per_launch") is not None:
+        cache["l2_hit_rate"] = cache["l2_hits_per_launch"] / max(cache["l2_hits_per_launch"] + cache["l2_misses_per_launch"], 1.0)
+    if cache:
+        entry["cache"] = cache
     fetch = next((p[dom]["FETCH_SIZE"] for p in passes.values() if dom in p and "FETCH_SIZE" in p[dom]), None)
     write = next((p[dom]["WRITE_SIZE"] for p in passes.values() if dom in p and "WRITE_SIZE" in p[dom]), None)
     if fetch is not None:
@@ -113,7 +135,19 @@ def main():
         for p in sorted(glob.glob(os.path.join(rd, "pmc", "*__*.csv"))):
             groups[os.path.basename(p).split("__", 1)[0]].append(p)
         for key, files in groups.items():
-            out[key.replace("-", "/")] = summarise(files)
+            e = summarise(files)
+            # the build the passes were taken with (rt_build_id, printed by bench.py into <key>__serial_bench.json) and, if
+            # present, the counting builds' totals (<key>__counts.json, tools/collect_counts.sh)
+            side = os.path.join(rd, key + "__serial_bench.json")
+            if os.path.exists(side):
+                try:
+                    e["build_id"] = json.load(open(side)).get("kernel", {}).get("build_id")
+                except Exception:
+                    pass
+            side = os.path.join(rd, key + "__counts.json")
+            if os.path.exists(side):
+                e["counts"] = json.load(open(side))
+            out[key.replace("-", "/")] = e
     path = os.path.join(ROOT, "profiles", "traffic.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     for k, v in out.items():
