@@ -227,9 +227,16 @@ def main():
     W, H, N, B = cfg["width"], cfg["height"], cfg["spheres"], cfg["bounces"]
     if not tri:
         scene = rt.synthetic_scene(N, cfg["seed"])
+    sky_name = "constant sky"
     if cfg["skybox"]:
-        png = os.path.join(ROOT, "assets", "daylight-skybox.png")    # the reference's asset, if the user supplies it
-        sky = rt.CubemapMaterial.from_png(png) if os.path.exists(png) else rt.CubemapMaterial.synthetic_daylight()
+        # C5: BASELINE.md names the reference's daylight-skybox.png; its six 512x512 faces (cubemap-material.ts:40-47) are
+        # the committed fixture tests/golden/ref_sky.png
+        from PIL import Image
+        import numpy as np
+        strip = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "ref_sky.png")).convert("RGBA"), dtype=np.uint8)
+        sky = rt.CubemapMaterial()
+        sky.faces = [np.ascontiguousarray(strip[:, k * strip.shape[0]:(k + 1) * strip.shape[0]]) for k in range(6)]
+        sky_name = "the reference's daylight sky box (6 x 512^2)"
     else:
         sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
     if ref_sky is not None:
@@ -287,7 +294,7 @@ def main():
     # hardware queue, the first gather on a buffer set for RCCL's and the runtime's lazy set-up: 7 ms that a
     # warm-up shorter than the rotation would leave inside the timed region), then the W warm-up steps.
     for _ in range(2 * FLIGHT):
-        step(False)
+        step(a.serial)                # (--serial: one at a time here too, so that a profiler sees launches of one kind only)
     fence()
     for _ in range(a.warmup):
         step(a.serial)
@@ -502,7 +509,7 @@ def main():
                                     "%d nodes; seed %d), %d bounces, constant sky, reference default camera/light"
                                     % (name, W, H, scene.triangleCount, len(scene.instances), scene.node_buffer_length(), cfg["seed"], B)) if tri else
                                    "%s: %dx%d, %d spheres (seed %d), %d bounces, %s, reference default camera/light"
-                                   % (name, W, H, N, cfg["seed"], B, "6x512^2 procedural sky cube" if cfg["skybox"] else "constant sky"),
+                                   % (name, W, H, N, cfg["seed"], B, sky_name),
                        "mode": a.mode, "variant": a.variant, "rays_per_frame": rays_frame,
                        "frames_in_flight": 1 if a.serial else FLIGHT,
                        "parallelism": "row-tiles x%d%s" % (world, "" if not multi else

@@ -95,6 +95,39 @@ def make_c5():
     json.dump(out, open(os.path.join(HERE, "c5_tiles.json"), "w"))
 
 
+def ref_sky():
+    """The six faces of the reference's daylight-skybox.png as committed by make_ref_scene.py (tests/golden/ref_sky.png)."""
+    from PIL import Image
+    strip = np.array(Image.open(os.path.join(HERE, "ref_sky.png")).convert("RGBA"), dtype=np.uint8)
+    m = rt.CubemapMaterial()
+    m.faces = [np.ascontiguousarray(strip[:, k * strip.shape[0]:(k + 1) * strip.shape[0]]) for k in range(6)]
+    return m
+
+
+def make_c5_ref_sky():
+    """C5 under the sky BASELINE.md names for it -- the reference's src/assets/images/daylight-skybox.png, cut as
+    cubemap-material.ts:35-58 cuts it -- instead of the procedural stand-in: the same ten tiles and sparse pixels."""
+    cfg = rt.BASELINE_CONFIGS["C5"]
+    W, H, N, B = cfg["width"], cfg["height"], cfg["spheres"], cfg["bounces"]
+    scene = rt.synthetic_scene(N, cfg["seed"])
+    p, s = scene.pack_params(B), scene.pack_spheres()
+    sky = ref_sky()
+    out = {"config": "C5", "sky": "tests/golden/ref_sky.png (daylight-skybox.png, six 512x512 faces)", "width": W, "height": H,
+           "spheres": N, "bounces": B, "seed": cfg["seed"],
+           "sky_sha256": hashlib.sha256(b"".join(np.ascontiguousarray(f).tobytes() for f in sky.faces)).hexdigest(),
+           "scene_sha256": hashlib.sha256(s.tobytes()).hexdigest(), "tiles": [], "pixels": []}
+    ntiles = (H + 7) // 8
+    for t in range(C5_TILE_FIRST, ntiles, C5_TILE_STEP):
+        img, _, rays = orc.render(p, s, sky.faces, W, H, tile_first=t, tile_step=ntiles)
+        out["tiles"].append({"tile": t, "sha256": hashlib.sha256(img[8 * t:8 * t + 8].tobytes()).hexdigest(), "rays": rays})
+        print("C5 (reference sky) tile", t, out["tiles"][-1], flush=True)
+    pts = sorted(set(c5_edge_pixels(p, W, H, sky.faces[0].shape[0], 64, 5) + sparse_pixels(W, H, 192, 1234 + N)), key=lambda q: (q[1], q[0]))
+    for (x, y) in pts:
+        rgb, rays = orc.pixel(p, s, sky.faces, W, H, x, y)
+        out["pixels"].append({"x": x, "y": y, "rgba8": [orc.unorm8(rgb[0]), orc.unorm8(rgb[1]), orc.unorm8(rgb[2]), 255], "rays": rays})
+    json.dump(out, open(os.path.join(HERE, "c5_ref_sky.json"), "w"))
+
+
 def make_c5_full():
     """The whole 7680x4320 C5 frame on the CPU (about ten minutes on 8 cores): adds its sha256 and ray
     count to c5_tiles.json and cross-checks the sampled tiles against the full frame."""
@@ -119,7 +152,11 @@ def main():
     ap.add_argument("--c3", action="store_true")
     ap.add_argument("--c5", action="store_true")
     ap.add_argument("--c5-full", action="store_true")
+    ap.add_argument("--c5-ref-sky", action="store_true")
     a = ap.parse_args()
+    if a.c5_ref_sky:
+        make_c5_ref_sky()
+        return
     if a.c5:
         make_c5()
         return

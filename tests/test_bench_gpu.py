@@ -61,6 +61,13 @@ def test_bench_headline_roofline_is_an_executed_fraction_below_one():
     assert 0.05 < r["serial"]["frac"] <= r["frac"] * 1.05 and d["serial_ms_per_step"] >= d["ms_per_step"] * 0.9
     assert d["algorithmic_speedup_vs_bruteforce"]["value"] > 1.0
     assert r["launches_in_flight"] == 4 and "bvh_pixels" in r["kernel"]
+    # verdict r2 item 4: the kernel is the one the library says it launched; what the issue slots are used FOR is reported
+    # beside the issue fraction; the line leads with what a caller gets
+    assert d["kernel"]["id"] == 4 and d["kernel"]["name"] == "bvh_pixels<8>" and len(d["kernel"]["build_id"]) == 16
+    u = r["useful"]
+    assert 0.0 < u["frac"] < r["frac"] and 0.3 < u["lanes_busy"] < 1.0
+    assert 30 < u["node_and_leaf_tests_per_ray"] < 70 and 1 < u["literal_tests_per_ray"] < 5
+    assert d["serial_ms_per_step"] <= d["readback_ms_per_step"] and abs(d["serial_value"] - d["config"]["rays_per_frame"] / d["serial_ms_per_step"] / 1e3) < 1.0
 
 
 def test_bench_distributed_path_with_one_rank():
@@ -98,6 +105,19 @@ def test_bench_serial_mode_times_single_launches():
     assert abs(r["time_ms"] - r["kernel_ms_avg"]) < 1e-9
     assert r["kernel_ms_avg"] <= d["ms_per_step"] * 1.05          # a launch is the bulk of a serial step
     assert abs(d["serial_ms_per_step"] - d["ms_per_step"]) < 1e-9
+
+
+def test_bench_reference_scene_config():
+    """`--config REF`: the reference's own scene in the state of its screenshot (tests/golden/ref_scene.npz), the window and
+    bounce count its overlay reports "6 ms" for; the timed frame is the oracle's frame, which is the screenshot's outside
+    the missing texture; an animated frame (instances rewritten every frame, RR:169-192) is reported beside the static one."""
+    d, _ = run_bench("--steps", "12", "--warmup", "2", "--config", "REF", "--cpu-seconds", "3")
+    assert "12604 triangles" in d["metric"] and d["config"]["workload"].startswith("REF: 1344x846")
+    assert d["frame_check"]["sha256_matches_oracle_frame"] is True and d["frame_check"]["sampled_tiles_match_oracle"] is True
+    assert d["kernel"]["name"] == "trace_triangles"
+    assert 0 < d["ms_per_step"] <= d["serial_ms_per_step"] * 1.05 < 6.0           # against the reference's 6 ms on its unnamed GPU
+    assert d["animated_ms_per_step"] >= d["serial_ms_per_step"] * 0.8 and d["animated_host_scene_update_ms"] > 0
+    assert d["cpu_baseline"]["kind"] == "port"
 
 
 def test_bench_triangle_config_prices_gathers_against_l2():

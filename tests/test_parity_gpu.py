@@ -429,6 +429,34 @@ def test_c5_full_size_against_golden_tiles_and_strict(oracle):
         assert st_fast["rays"] == g["frame_rays"]
 
 
+def test_c5_full_size_under_the_reference_skybox(oracle):
+    """BASELINE.md names the sky of C5: the reference's src/assets/images/daylight-skybox.png, cut into six 512x512
+    faces as cubemap-material.ts:35-58 does.  Those faces are a committed fixture (tests/golden/ref_sky.png, the sky
+    the oracle is pinned under by the reference's screenshot, tests/test_ref_pin.py); the oracle's rows for ten tiles
+    and 256 sparse pixels of the full-size C5 frame under them are in tests/golden/c5_ref_sky.json."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = json.load(open(os.path.join(G, "c5_ref_sky.json")))
+    cfg, scene = config_inputs("C5")
+    sky = mg.ref_sky()
+    assert hashlib.sha256(b"".join(np.ascontiguousarray(f).tobytes() for f in sky.faces)).hexdigest() == g["sky_sha256"]
+    assert hashlib.sha256(scene.pack_spheres().tobytes()).hexdigest() == g["scene_sha256"]
+    W, H, B = cfg["width"], cfg["height"], cfg["bounces"]
+    fast, st = gpu_render(scene, W, H, B, strict=False, skybox=sky)
+    for t in g["tiles"]:
+        rows = fast[8 * t["tile"]:8 * t["tile"] + 8]
+        if hashlib.sha256(rows.tobytes()).hexdigest() != t["sha256"]:
+            ref, _, _ = oracle_render(oracle, scene, W, H, B, skybox=sky, tile_first=t["tile"], tile_step=(H + 7) // 8)
+            bad = np.argwhere((rows != ref[8 * t["tile"]:8 * t["tile"] + 8]).any(-1))
+            raise AssertionError("C5 (reference sky) tile %d differs from the oracle at %d pixels, first (row, x) %s"
+                                 % (t["tile"], len(bad), bad[:4].tolist()))
+    for px in g["pixels"]:
+        assert list(fast[px["y"], px["x"]]) == px["rgba8"], px
+    assert np.all(fast[..., 3] == 255) and st["kernel_id"] == 6            # the 16-wave hierarchy form
+
+
 def test_c5_eight_emulated_ranks_reassemble_the_one_rank_frame():
     """C5 is specified on 8 GPUs: 540 tiles -> 68 / 67 per rank.  One GPU plays the 8 ranks in turn;
     the de-interleaved frame must equal the frame one rank renders alone, ray counts must add up."""
