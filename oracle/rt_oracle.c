@@ -1,7 +1,7 @@
 /*
  * rt_oracle.c -- CPU restatement of the reference's per-pixel ray-trace shader
- * with the sphere primitive.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see
- * rt_oracle.h for both statements and for the arithmetic conventions).
+ * with the sphere primitive.  TEST INFRASTRUCTURE ONLY; what pins it -- the reference's screenshot -- and
+ * the arithmetic conventions are stated in rt_oracle.h.
  *
  * Build:  gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC
  *         (see oracle/Makefile).  Never -march=native / -mfma / -ffast-math.

@@ -1,7 +1,7 @@
 """rt_oracle_np.py -- an INDEPENDENT numpy restatement of the reference shader (sphere path),
 vectorised over pixels, written separately from oracle/rt_oracle.c to catch restatement bugs.
 
-TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (the reference ships no fixtures).
+TEST INFRASTRUCTURE ONLY; parity: see rt_oracle.h (the C oracle is pinned by the reference's screenshot; this twin follows it bit for bit).
 It cannot pin the C oracle to the reference; it only shows that two separate readings of
 the WGSL agree bit for bit.  All arithmetic is numpy float32 (IEEE single operations, no
 fusion), in the order the WGSL grammar gives.

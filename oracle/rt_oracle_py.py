@@ -1,6 +1,6 @@
 """ctypes wrapper around oracle/librt_oracle.so.  TEST INFRASTRUCTURE ONLY (see rt_oracle.h):
 importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from
-the product package.  PARITY UNPINNED (no reference fixtures exist)."""
+the product package.  Pinned by the reference's one held output, its screenshot (rt_oracle.h; tests/test_ref_pin.py)."""
 import ctypes
 import os
 import subprocess

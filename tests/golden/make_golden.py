@@ -3,7 +3,8 @@
 
 The reference repository holds no tests, golden images or known-answer vectors for this path
  and cannot be executed offline, so these vectors pin the ORACLE (and through
-it the HIP kernels) against regressions; they are not outputs of the reference.  PARITY UNPINNED.
+it the HIP kernels) against regressions; they are not outputs of the reference (the one output the reference holds --
+its screenshot -- pins the oracle itself: make_ref_scene.py, tests/test_ref_pin.py).
 
     python tests/golden/make_golden.py            # C1, C2 (seconds)
     python tests/golden/make_golden.py --c3       # also the full C3 frame hash (about a minute of CPU)

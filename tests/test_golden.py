@@ -1,5 +1,5 @@
 """The oracle against the committed golden vectors (tests/golden/, written by make_golden.py
-from this same oracle: regression pins, not outputs of the reference -- PARITY UNPINNED)."""
+from this same oracle: regression pins, not outputs of the reference; the reference's own output is tests/test_ref_pin.py)."""
 import hashlib
 import json
 import os

@@ -1,6 +1,6 @@
 """Known-answer tests of the CPU oracle against hand-derivable anchors.
 
-The reference has no fixtures for this path (PARITY UNPINNED); these KATs pin the oracle to
+The reference holds no test vectors (its one output, a screenshot, pins whole frames: tests/test_ref_pin.py); these KATs pin the oracle to
 the reference's *text*: each case states the WGSL line whose behaviour it checks.
 RK = src/rendering-raycast/shaders/raytracer-kernel.wgsl, HK = .../heatmap-kernel.wgsl.
 """

@@ -1,6 +1,6 @@
 """The C oracle against the independent numpy restatement (oracle/rt_oracle_np.py): two
 separately written readings of the WGSL must agree bit for bit, pre-quantisation floats
-included.  (PARITY UNPINNED: neither is pinned by a fixture of the reference)"""
+included.  (The sphere primitive is dead code upstream: this cross-check, not the screenshot of tests/test_ref_pin.py, is what stands behind it.)"""
 import numpy as np
 import pytest
 
