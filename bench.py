@@ -333,13 +333,30 @@ def main():
     # what a host that READS every frame gets (render, wait, copy the frame to pageable host memory: the PCIe-inclusive
     # rate -- never `value`), and, for a triangle scene, what the reference's animation loop costs (scene.update on the
     # host, the per-frame writes of RR:169-192, render, wait: src/app.ts:117-128)
-    readback_ms = animated_ms = animated_host_ms = None
+    readback_ms = streamed_ms = animated_ms = animated_host_ms = None
     if not multi and ssteps > 0:
         r.enqueue(); r.wait(); r.read_pixels()
         t0 = time.perf_counter()
         for _ in range(ssteps):
             r.enqueue(); r.wait(); r.read_pixels()
         readback_ms = (time.perf_counter() - t0) / ssteps * 1e3
+        # ... and frames in flight WITH every frame copied out: the streaming read-back (rt_read_pixels_async) copies frame
+        # i - 2 to pinned host memory while frames i - 1 and i render
+        host = r.host_frames(4)
+        def streamed(n):
+            fence()
+            t0 = time.perf_counter()
+            for i in range(n):
+                if i and i % 48 == 0:
+                    r.wait()                              # the library's event ring holds 64 frames
+                r.enqueue()
+                if i >= 2:
+                    r.read_pixels_async(2, host[i % 4])
+            r.read_pixels_async(1, host[(n + 2) % 4]); r.read_pixels_async(0, host[(n + 3) % 4])
+            r.wait(); r.read_pixels_wait()
+            return (time.perf_counter() - t0) / n * 1e3
+        streamed(8)
+        streamed_ms = streamed(max(ssteps, 24))
         if tri:
             pose = scene.instances.eulers.copy()
             t0 = time.perf_counter()
@@ -496,6 +513,7 @@ def main():
             "serial_ms_per_step": serial_ms,
             "serial_value": (rays_frame / (serial_ms * 1e-3) / 1e6) if serial_ms else None,
             "readback_ms_per_step": readback_ms,
+            "streamed_readback_ms_per_step": streamed_ms,
             "animated_ms_per_step": animated_ms,
             "animated_host_scene_update_ms": animated_host_ms if animated_ms is not None else None,
             "kernel": {"id": int(kid_main), "name": label, "serial_id": int(kid_serial), "build_id": build_id},

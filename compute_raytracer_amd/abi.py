@@ -33,6 +33,7 @@ SYMBOLS = [
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_render_gather", "rt_frame_pixels", "rt_read_frame",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_ctx", "rt_group_render", "rt_group_wait",
     "rt_build_id", "rt_kernel_name", "rt_set_comm_timeout",
+    "rt_read_pixels_async", "rt_read_pixels_wait", "rt_host_alloc", "rt_host_free",
 ]
 
 # rt_kernel_id (include/rt355.h): which kernel form rendered a frame
@@ -140,6 +141,10 @@ def load():
         "rt_build_id": (ctypes.c_char_p, []),
         "rt_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
         "rt_set_comm_timeout": (ctypes.c_int, [vp, u32]),
+        "rt_read_pixels_async": (ctypes.c_int, [vp, u32, vp, sz]),
+        "rt_read_pixels_wait": (ctypes.c_int, [vp]),
+        "rt_host_alloc": (ctypes.c_int, [sz, ctypes.POINTER(vp)]),
+        "rt_host_free": (ctypes.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -181,6 +181,8 @@ int rt_create(int device, rt_ctx** out) {
     for (int k = 0; k < kStreams && err == hipSuccess; ++k) err = hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking);
     c->stream = c->streams[0];
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->ev_scene, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    for (int k = 0; k < kStreams && err == hipSuccess; ++k) err = hipEventCreateWithFlags(&c->ev_copy[k], hipEventDisableTiming);
     for (int i = 0; i < RT355_MAX_IN_FLIGHT && err == hipSuccess; ++i) {
         if ((err = hipEventCreate(&c->ev_prep0[i])) != hipSuccess) break;
         if ((err = hipEventCreate(&c->ev_k0[i])) != hipSuccess) break;
@@ -205,6 +207,9 @@ int rt_destroy(rt_ctx* c) {
     for (uint32_t i = 0; i < c->in_flight; ++i) (void)hipEventSynchronize(c->ev_k1[i]);
     for (int k = 0; k < kStreams; ++k)
         if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (int k = 0; k < kStreams; ++k)
+        if (c->ev_copy[k]) (void)hipEventDestroy(c->ev_copy[k]);
     rt_comm_release(c);
     delete c->rebuild;
     c->rebuild = nullptr;
@@ -234,6 +239,7 @@ int rt_destroy(rt_ctx* c) {
 }
 
 int rt_wait(rt_ctx* c);
+int rt_read_pixels_wait(rt_ctx* c);
 uint32_t rt_local_tiles(const rt_ctx* c) { return rt_tiles_of_rank(c->H, c->rank, c->world); }
 static uint32_t local_tiles(const rt_ctx* c) { return rt_local_tiles(c); }
 
@@ -249,7 +255,12 @@ uint32_t rt_padded_tiles(uint32_t height, uint32_t world) {
 }
 
 // Scene-setup calls change device state that frames in flight may read: they drain first.
-int rt_drain(rt_ctx* c) { return c->in_flight ? rt_wait(c) : RT_OK; }
+int rt_drain(rt_ctx* c) {
+    bool copies = false;
+    for (int k = 0; k < kStreams; ++k) copies = copies || c->copy_pending[k];
+    if (copies) { int rc = rt_read_pixels_wait(c); if (rc != RT_OK) return rc; }
+    return c->in_flight ? rt_wait(c) : RT_OK;
+}
 static int drain(rt_ctx* c) { return rt_drain(c); }
 
 static int ensure_out(rt_ctx* c) {
@@ -807,8 +818,10 @@ int rt_render(rt_ctx* c) {
     // back to back overlap on the device; rt_read_pixels returns the latest one
     const uint32_t k = c->frames_rendered % (uint32_t)kStreams;
     uint8_t* dst = c->d_outs[k];
+    // a streaming read-back (rt_read_pixels_async) may still be copying the frame this buffer holds
+    if (c->copy_pending[k]) RT_HIP(hipStreamWaitEvent(c->streams[k], c->ev_copy[k], 0));
     int rc = rt_enqueue(c, dst, c->streams[k]);
-    if (rc == RT_OK) { c->d_out = dst; ++c->frames_rendered; }
+    if (rc == RT_OK) { c->d_out = dst; c->buf_slot[k] = (int)c->in_flight - 1; ++c->frames_rendered; }
     return rc;
 }
 
@@ -876,6 +889,7 @@ int rt_wait(rt_ctx* c) {
         }
         (void)hipGetLastError();
         c->in_flight = 0;
+        for (int k = 0; k < kStreams; ++k) c->buf_slot[k] = -1;      // every frame of the batch is complete
         // a kernel that could not run as planned says so in the word behind its first ray counter (rt_device.h: report_fault)
         const unsigned long long fault = c->h_rays[1];
         if (fault != 0ull) {
@@ -907,6 +921,43 @@ int rt_read_pixels(rt_ctx* c, uint8_t* dst, size_t cap) {
     if (cap < need) return fail(RT_ERR_CAPACITY, "rt_read_pixels: destination smaller than the local rows * W * 4");
     RT_HIP(hipMemcpyAsync(dst, c->d_out, need, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_pixels_async(rt_ctx* c, uint32_t frames_back, uint8_t* dst, size_t cap) {
+    if (!c || !dst) return fail(RT_ERR_INVALID_ARG, "rt_read_pixels_async: NULL argument");
+    if (frames_back >= (uint32_t)kStreams || frames_back >= c->frames_rendered)
+        return fail(RT_ERR_INVALID_ARG, "rt_read_pixels_async: frames_back must name one of the last four rt_render calls");
+    if (c->world != 1u || c->comm) return fail(RT_ERR_STATE, "rt_read_pixels_async: whole-frame contexts only");
+    if (!c->d_outs[0]) return fail(RT_ERR_STATE, "rt_read_pixels_async: no colour buffer (rt_resize first)");
+    const size_t need = (size_t)c->H * c->W * 4u;
+    if (cap < need) return fail(RT_ERR_CAPACITY, "rt_read_pixels_async: destination smaller than H * W * 4");
+    RT_HIP(hipSetDevice(c->device));
+    const uint32_t k = (c->frames_rendered - 1u - frames_back) % (uint32_t)kStreams;
+    if (c->buf_slot[k] >= 0) RT_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_k1[c->buf_slot[k]], 0));   // behind that frame's kernels
+    RT_HIP(hipMemcpyAsync(dst, c->d_outs[k], need, hipMemcpyDeviceToHost, c->copy_stream));
+    RT_HIP(hipEventRecord(c->ev_copy[k], c->copy_stream));
+    c->copy_pending[k] = true;
+    return RT_OK;
+}
+
+int rt_read_pixels_wait(rt_ctx* c) {
+    if (!c) return fail(RT_ERR_INVALID_ARG, "rt_read_pixels_wait: ctx is NULL");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->copy_stream));
+    for (int k = 0; k < kStreams; ++k) c->copy_pending[k] = false;
+    return RT_OK;
+}
+
+int rt_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(RT_ERR_INVALID_ARG, "rt_host_alloc: NULL / zero size");
+    *out = nullptr;
+    RT_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return RT_OK;
+}
+
+int rt_host_free(void* p) {
+    if (p) RT_HIP(hipHostFree(p));
     return RT_OK;
 }
 

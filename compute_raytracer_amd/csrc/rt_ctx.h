@@ -83,6 +83,12 @@ struct rt_ctx {
     uint32_t face_texel0[6] = {0, 0, 0, 0, 0, 0};   // first texel (rgb) of each face: a one-texel sky of one colour is "flat"
     uint8_t* d_out = nullptr;              // colour buffer of the LATEST rt_render (one of d_outs)
     uint8_t* d_outs[kStreams] = {nullptr};
+    // streaming read-back (rt_read_pixels_async): a copy stream, per colour buffer the event of the last copy out of it and the
+    // event slot of the frame of the current batch that renders into it (-1: none in flight)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy[kStreams] = {nullptr};
+    bool copy_pending[kStreams] = {false};
+    int buf_slot[kStreams] = {-1, -1, -1, -1};
     float4* d_fin[kStreams] = {nullptr};         // end-of-path records of frames with a textured sky (rt_bvh.hip: sky_resolve), lazily
     size_t fin_slots = 0;                        // pixel slots each of them holds
     size_t out_bytes = 0;

@@ -33,6 +33,7 @@ class RendererRaytracing:
         self.render_time_ms = None             # the 'render-time' label of RR:468-469
         self._ctx = None
         self._lib = None
+        self._pinned = []
 
     # ---- RR:62-68 -------------------------------------------------------------------------
     def initialize(self, skybox=None, meshMaterial=None):
@@ -128,6 +129,25 @@ class RendererRaytracing:
         abi.check(self._lib.rt_read_pixels(self._ctx, out.ctypes.data, out.nbytes), self._ctx)
         return out
 
+    # ---- streaming read-back: frames in flight AND copied out (rt_read_pixels_async) -----------
+    def host_frames(self, n):
+        """n pinned (H, W, 4) uint8 frames for read_pixels_async (freed by close())."""
+        nbytes = self.height * self.width * 4
+        out = []
+        for _ in range(n):
+            p = ctypes.c_void_p()
+            abi.check(self._lib.rt_host_alloc(nbytes, ctypes.byref(p)))
+            self._pinned.append(p)
+            buf = (ctypes.c_uint8 * nbytes).from_address(p.value)
+            out.append(np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 4))
+        return out
+
+    def read_pixels_async(self, frames_back, dst):
+        abi.check(self._lib.rt_read_pixels_async(self._ctx, int(frames_back), dst.ctypes.data, dst.nbytes), self._ctx)
+
+    def read_pixels_wait(self):
+        abi.check(self._lib.rt_read_pixels_wait(self._ctx), self._ctx)
+
     def stats(self):
         st = abi.RtStats()
         abi.check(self._lib.rt_get_stats(self._ctx, ctypes.byref(st)), self._ctx)
@@ -177,6 +197,9 @@ class RendererRaytracing:
         if self._ctx is not None:
             self._lib.rt_destroy(self._ctx)
             self._ctx = None
+            for p in self._pinned:
+                self._lib.rt_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:

@@ -217,6 +217,18 @@ int rt_wait(rt_ctx* ctx);
  * Needs cap >= local_tiles*8*W*4 clipped to the frame. */
 int rt_read_pixels(rt_ctx* ctx, uint8_t* dst, size_t cap);
 
+/* Streaming read-back: frames kept in flight AND copied out.  rt_read_pixels returns the latest frame only and waits;
+ * a host that wants every frame of a pipelined sequence begins an asynchronous copy per frame instead: the frame
+ * `frames_back` rt_render calls ago (0 = the latest, at most 3 -- the library rotates over four colour buffers) is copied
+ * to `dst` on a copy stream of the library's own, behind that frame's kernels and beside the rendering of the frames
+ * after it; a later frame that would overwrite the colour buffer waits for the copy, nothing else does.  `dst` should be
+ * pinned memory (rt_host_alloc) -- with pageable memory the copy is staged and the call may block.  rt_read_pixels_wait
+ * returns when every copy begun so far has landed.  Whole-frame contexts only (no partition, no rt_render_gather). */
+int rt_read_pixels_async(rt_ctx* ctx, uint32_t frames_back, uint8_t* dst, size_t cap);
+int rt_read_pixels_wait(rt_ctx* ctx);
+int rt_host_alloc(size_t bytes, void** out);   /* pinned host memory (hipHostMalloc) */
+int rt_host_free(void* p);
+
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);
 
 /* ---- device-pointer interop (process-per-GPU hosts: torch.distributed / RCCL) --------- */

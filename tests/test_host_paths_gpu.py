@@ -127,3 +127,32 @@ def test_communicator_of_one_completes_under_a_deadline(oracle):
         assert np.array_equal(r.read_frame(), ref2)
     finally:
         r.close()
+
+
+def test_streaming_readback_delivers_every_frame_of_a_pipelined_sequence(oracle):
+    """Frames enqueued back to back rotate over four colour buffers; rt_read_pixels returns the latest only.  The streaming
+    read-back copies EVERY frame out while the next ones render (round-2 verdict: "three of every four pipelined frames can
+    never be read"): eleven frames, each with its own camera, each must arrive intact."""
+    W, H, N, B, K = 480, 270, 300, 4, 11
+    r = _renderer(W, H, N, B)
+    try:
+        host = r.host_frames(K)
+        refs = []
+        for f in range(K):
+            r.scene.camera.move(0.07, -0.03)
+            refs.append(oracle.render(r.scene.pack_params(B), r.scene.pack_spheres(), r.skyboxMaterial.faces, W, H)[0])
+            r.recalculateScene()                              # params only: no drain
+            r.enqueue()
+            if f >= 2:
+                r.read_pixels_async(2, host[f - 2])           # the frame two renders back: three frames stay in flight
+        r.read_pixels_async(1, host[K - 2])
+        r.read_pixels_async(0, host[K - 1])
+        r.wait()
+        r.read_pixels_wait()
+        for f in range(K):
+            assert np.array_equal(host[f], refs[f]), f
+        L = abi.load()
+        assert L.rt_read_pixels_async(r._ctx, 4, host[0].ctypes.data, host[0].nbytes) == abi.RT_ERR_INVALID_ARG
+        assert L.rt_read_pixels_async(r._ctx, 0, host[0].ctypes.data, 16) == abi.RT_ERR_CAPACITY
+    finally:
+        r.close()
