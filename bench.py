@@ -146,8 +146,8 @@ def cpu_baseline_tri(cfg, scene, mat, sky, target_s, gpu_frame):
         "sample": "oracle/rt_oracle.c triangle path (scalar fp32 C, OpenMP over rows) on %d of %d 8-row tiles (every %d-th) "
                   "of the same %dx%d / %d-triangle / %d-bounce frame: %d rays in %.1f s" % (n, ntiles, step, W, H, scene.triangleCount, B, rays, dt),
         "fps_equiv": (n / ntiles) / dt,
-        "gather_bytes_per_ray": (32.0 * nodes + 160.0 * tests + 80.0 * blas) / max(rays, 1),
-        "per_ray": {"node_loads_32B": nodes / max(rays, 1), "triangle_tests_160B": tests / max(rays, 1), "instance_records_80B": blas / max(rays, 1)},
+        "gather_bytes_per_ray": (32.0 * nodes + 48.0 * tests + 80.0 * blas) / max(rays, 1),
+        "per_ray": {"node_loads_32B": nodes / max(rays, 1), "triangle_tests_48B": tests / max(rays, 1), "instance_records_80B": blas / max(rays, 1)},
         "gpu_rows_match": bool(np.array_equal(gpu_frame[rows], img[rows])) if gpu_frame is not None else None,
     }
 
@@ -477,25 +477,33 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_tri(cfg, scene, mat, sky, a.cpu_seconds, tri_frame) if tri else cpu_baseline(cfg, scene, sky, a.cpu_seconds)
         if tri:
-            # The triangle kernel is a pointer chase: per ray it gathers 32-B nodes, 160-B triangles and 80-B instance
-            # records (counted by the oracle on the sampled tiles, same frame).  The scene (2.9 MB) lives in L2, so
-            # the gathers are priced against the L2 roof; the VALU view stays in `valu` when a PMC pass exists.
+            # The triangle kernel is a pointer chase: a node pair per step, ~17 dependent steps per ray.  Its memory side is
+            # MEASURED (TCP / TCC passes of tools/collect_profiles.sh, profiles/traffic.json[...]["cache"]): `achieved` = L1 -> L2
+            # read requests x 64 B per launch / time against the aggregate L2 bandwidth -- a fraction of a per cent: no
+            # bandwidth binds this kernel, the latency of the dependent loads does (`l2.wait_share`: the part of the
+            # wave-cycles spent in s_waitcnt).  What the lanes REQUEST (counted by the oracle on the sampled tiles: 32-B
+            # nodes, 48-B corner triples, 80-B instance records) is kept as `requested`: the L1 absorbs most of it.
             valu_view = {k: roof.get(k) for k in ("achieved", "frac", "valu_wave_insts_per_launch", "from_profile", "serial") if k in roof}
-            roof = {"bound": "l2-gather", "kernel": label, "peak": PEAK_L2_GBPS, "unit": "GB/s", "kernel_ms_avg": kernel_ms,
+            cache = (prof or {}).get("cache") or {}
+            roof = {"bound": "latency of dependent loads (L1 / L2 gathers)", "kernel": label, "peak": PEAK_L2_GBPS, "unit": "GB/s", "kernel_ms_avg": kernel_ms,
                     "time_ms": roof_ms, "launches_in_flight": FLIGHT if overlapping else 1, "traffic": (prof or {}).get("hbm_bytes_per_launch"),
-                    "valu": valu_view, "hbm": roof["hbm"]}
+                    "valu": valu_view, "hbm": roof["hbm"], "achieved": None, "frac": None}
+            if cache.get("l2_read_bytes_per_launch"):
+                ach = cache["l2_read_bytes_per_launch"] / (roof_ms * 1e-3) / 1e9
+                roof.update({"achieved": ach, "frac": ach / PEAK_L2_GBPS,
+                             "l2": {"read_bytes_per_launch": cache["l2_read_bytes_per_launch"], "hit_rate": cache.get("l2_hit_rate"),
+                                    "mean_read_latency_cycles": cache.get("mean_l2_read_latency_cycles"),
+                                    "wait_share": (cache["wait_any_per_launch"] / executed["wave_cycles_per_launch"])
+                                    if cache.get("wait_any_per_launch") and executed.get("wave_cycles_per_launch") else None},
+                             "basis": "achieved = TCP_TCC_READ_REQ_sum x 64 B per launch (PMC pass of one-frame-at-a-time launches, from_profile) / time_ms; "
+                                      "peak = aggregate L2 bandwidth (34.5 TB/s).  The kernel is latency-bound: see l2.wait_share and `valu`"})
+            else:
+                roof["basis"] = stale_note or "no TCP / TCC pass for %s under profiles/" % prof_key
             if cpu is not None:
                 gbytes = cpu["gather_bytes_per_ray"] * rays_kernel
-                ach = gbytes / (roof_ms * 1e-3) / 1e9
-                roof.update({"achieved": ach, "frac": ach / PEAK_L2_GBPS, "gather_bytes_per_launch": gbytes,
-                             "gathers_per_ray": cpu["per_ray"],
-                             "basis": "achieved = (32 B x node loads + 160 B x triangle tests + 80 B x instance records) per ray, counted by "
-                                      "the oracle on the sampled tiles of this frame, x rays per launch / time_ms; peak = aggregate L2 bandwidth. "
-                                      "The bytes are what the lanes REQUEST: lanes of a wave that read the same node are served by one "
-                                      "L1 line, so this is an upper bound of the L2 traffic (frac near 1 means the request stream, not L2, "
-                                      "is saturated); `valu` is the executed-instruction fraction of the same launch"})
-            else:
-                roof.update({"achieved": None, "frac": None, "basis": "gather counts come from the cpu_baseline leg (--no-cpu-baseline given)"})
+                roof["requested"] = {"achieved": gbytes / (roof_ms * 1e-3) / 1e9, "frac": gbytes / (roof_ms * 1e-3) / 1e9 / PEAK_L2_GBPS,
+                                     "gather_bytes_per_launch": gbytes, "gathers_per_ray": cpu["per_ray"],
+                                     "note": "bytes the lanes ask for, lane by lane (an upper bound of any cache level's traffic)"}
             check = {"sampled_tiles_match_oracle": cpu["gpu_rows_match"]} if cpu is not None else None
             if cfg.get("fixture") and tri_frame is not None:
                 pin = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_pin.json")))

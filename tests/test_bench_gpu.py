@@ -128,8 +128,13 @@ def test_bench_triangle_config_prices_gathers_against_l2():
     d, _ = run_bench("--steps", "6", "--warmup", "2", "--config", "TRI", "--cpu-seconds", "4")
     assert "triangles" in d["metric"] and d["config"]["rays_per_frame"] > 1344 * 846
     r = d["roofline"]
-    assert r["bound"] == "l2-gather" and r["unit"] == "GB/s" and r["peak"] == 34500.0
-    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["gathers_per_ray"]["node_loads_32B"] > 5 and r["gathers_per_ray"]["triangle_tests_160B"] > 0.5
+    assert r["bound"].startswith("latency") and r["unit"] == "GB/s" and r["peak"] == 34500.0
+    if r["frac"] is not None:      # measured L2 read traffic (TCP / TCC passes of this build): a small fraction of the L2 roof
+        assert 0.0 < r["frac"] < 0.2 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert 0.3 < r["l2"]["hit_rate"] <= 1.0 and r["l2"]["mean_read_latency_cycles"] > 50
+    else:
+        assert "re-run tools/collect_profiles.sh" in r["basis"] or "no TCP / TCC pass" in r["basis"]
+    q = r["requested"]
+    assert q["gathers_per_ray"]["node_loads_32B"] > 5 and q["gathers_per_ray"]["triangle_tests_48B"] > 0.5 and q["frac"] > 0
     assert d["frame_check"]["sampled_tiles_match_oracle"] is True
     assert d["cpu_baseline"]["kind"] == "port" and "triangle path" in d["cpu_baseline"]["sample"]
