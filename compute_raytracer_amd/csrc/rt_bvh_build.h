@@ -128,6 +128,23 @@ struct Builder {
             if (!(Rq < Rp)) break;
             P[0] = Q[0]; P[1] = Q[1]; P[2] = Q[2]; Rp = Rq; far = far_q;
         }
+        // ... then towards the farthest member with a shrinking step (Badoiu-Clarkson: converges on the smallest enclosing
+        // ball; the greedy walk above stops at its first non-improvement, typically 2 % in radius short of it), keeping
+        // the best centre seen.  Any centre is valid -- the radius is measured afterwards --, a smaller ball is passed by fewer rays.
+        if (hi - lo > 2u) {
+            double Q[3] = {P[0], P[1], P[2]};
+            for (int it = 1; it <= 96; ++it) {
+                uint32_t fq = far;
+                const double Rq = radius_at(Q, fq);
+                if (Rq < Rp) { Rp = Rq; P[0] = Q[0]; P[1] = Q[1]; P[2] = Q[2]; }
+                const double s[3] = {cx(fq, 0) - Q[0], cx(fq, 1) - Q[1], cx(fq, 2) - Q[2]};
+                const double len = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+                if (!(len > 1e-12)) break;
+                // the farthest POINT of the farthest member: its centre pushed out by its radius
+                const double k = (1.0 + rad(fq) / len) / (double)(it + 1);
+                Q[0] += s[0] * k; Q[1] += s[1] * k; Q[2] += s[2] * k;
+            }
+        }
         const float C[3] = {(float)P[0], (float)P[1], (float)P[2]};   // the record stores the centre in fp32:
         const double Cd[3] = {C[0], C[1], C[2]};                       // the radius is taken about THAT point
         uint32_t unused = 0;
