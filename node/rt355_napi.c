@@ -558,6 +558,77 @@ static napi_value CommDestroy(napi_env env, napi_callback_info info) {
 
 INT_SETTER(RenderGather, rt_render_gather)
 
+/* ---- streaming read-back (rt_read_pixels_async): pinned Uint8Arrays owned by the addon ------------------------------ */
+static void pinned_finalize(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    if (data) rt_host_free(data);
+}
+
+/* hostAlloc(bytes) -> Uint8Array over pinned host memory (hipHostMalloc), freed when the array is collected */
+static napi_value HostAlloc(napi_env env, napi_callback_info info) {
+    napi_value argv[1], ab, u8;
+    uint32_t bytes = 0;
+    void* p = NULL;
+    if (!get_args(env, info, 1, argv) || !get_u32(env, argv[0], &bytes)) return NULL;
+    int rc = rt_host_alloc(bytes, &p);
+    if (rc != RT_OK) return throw_status(env, rc, NULL);
+    if (napi_create_external_arraybuffer(env, p, bytes, pinned_finalize, NULL, &ab) != napi_ok ||
+        napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &u8) != napi_ok) {
+        rt_host_free(p);
+        napi_throw_error(env, NULL, "rt355: cannot wrap the pinned buffer");
+        return NULL;
+    }
+    return u8;
+}
+
+/* readPixelsAsync(ctx, framesBack, Uint8Array): the copy runs beside the rendering of the next frames; the array must
+ * stay reachable until readPixelsWait(ctx) has returned */
+static napi_value ReadPixelsAsync(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    void* data; size_t len;
+    uint32_t back = 0;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_u32(env, argv[1], &back) || !get_typed(env, argv[2], napi_uint8_array, &data, &len)) return NULL;
+    int rc = rt_read_pixels_async(ctx, back, (uint8_t*)data, len);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value ReadPixelsWait(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int rc = rt_read_pixels_wait(ctx);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+/* setCommTimeout(ctx, ms): deadline of wait() on a context with a communicator (0: RCCL errors only) */
+static napi_value SetCommTimeout(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    uint32_t ms = 0;
+    if (!get_args(env, info, 2, argv)) return NULL;
+    rt_ctx* ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_u32(env, argv[1], &ms)) return NULL;
+    int rc = rt_set_comm_timeout(ctx, ms);
+    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+}
+
+static napi_value BuildId(napi_env env, napi_callback_info info) {
+    (void)info;
+    napi_value s;
+    napi_create_string_utf8(env, rt_build_id(), NAPI_AUTO_LENGTH, &s);
+    return s;
+}
+
+static napi_value KernelName(napi_env env, napi_callback_info info) {
+    napi_value argv[1], s;
+    uint32_t id = 0;
+    if (!get_args(env, info, 1, argv) || !get_u32(env, argv[0], &id)) return NULL;
+    napi_create_string_utf8(env, rt_kernel_name((int)id), NAPI_AUTO_LENGTH, &s);
+    return s;
+}
+
 static napi_value AbiVersion(napi_env env, napi_callback_info info) {
     (void)info;
     napi_value n;
@@ -573,7 +644,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"writeTriLookup", WriteTriLookup}, {"writeBlasLookup", WriteBlasLookup}, {"writeMeshTexture", WriteMeshTexture},
         {"setMode", SetMode}, {"setVariant", SetVariant}, {"setPartition", SetPartition}, {"render", Render},
         {"wait", Wait}, {"waitSync", WaitSync}, {"readPixels", ReadPixels}, {"stats", Stats},
-        {"abiVersion", AbiVersion},
+        {"abiVersion", AbiVersion}, {"buildId", BuildId}, {"kernelName", KernelName},
+        {"hostAlloc", HostAlloc}, {"readPixelsAsync", ReadPixelsAsync}, {"readPixelsWait", ReadPixelsWait}, {"setCommTimeout", SetCommTimeout},
         {"readFrame", ReadFrame}, {"createGroup", CreateGroup}, {"destroyGroup", DestroyGroup}, {"groupSize", GroupSize},
         {"groupCtx", GroupCtx}, {"groupRender", GroupRender}, {"groupWait", GroupWait}, {"groupWaitSync", GroupWaitSync},
         {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"renderGather", RenderGather},

@@ -30,7 +30,8 @@ def test_addon_loads_and_exports():
     assert ver == 3
     for n in ["create", "destroy", "resize", "writeParams", "writeSpheres", "writeCubemapFace", "selectKernel",
               "setMode", "setPartition", "render", "wait", "readPixels", "stats", "readFrame", "createGroup", "destroyGroup",
-              "groupSize", "groupCtx", "groupRender", "groupWait", "commUniqueId", "commInit", "renderGather"]:
+              "groupSize", "groupCtx", "groupRender", "groupWait", "commUniqueId", "commInit", "renderGather", "hostAlloc",
+              "readPixelsAsync", "readPixelsWait", "setCommTimeout", "buildId", "kernelName"]:
         assert n in names
 
 
@@ -276,3 +277,33 @@ def test_node_builds_and_renders_obj_scene(tmp_path, oracle):
     sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
     ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, rt.Material(tex)), sky.faces, W, H)
     assert js["rays"] == rays and js["sha256"] == hashlib.sha256(ref.tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+def test_node_streaming_readback(oracle):
+    """The animation loop of src/app.ts:117-128 with frames in flight AND every frame on the host, from Node: render without
+    awaiting, copy the frame two renders back into a pinned Uint8Array (hostAlloc / readPixelsAsync), wait at the end; each of
+    the eight frames (the camera walks) must be the oracle's."""
+    W, H, B, K = 200, 120, 3, 8
+    out = run_node("""
+const rt=require('./node/rt355.node'); const crypto=require('crypto');
+const s=require('./node/scene-raytracing'); const {RendererRaytracing}=require('./node/renderer-raytracing');
+(async()=>{
+  const scene=new s.SceneRaytracing(); await scene.createScene(s.syntheticSpheres(300,361));
+  const r=new RendererRaytracing(%d,%d,scene,{maxBounces:%d}); await r.initialize();
+  const host=[]; for(let i=0;i<%d;++i) host.push(rt.hostAlloc(%d));
+  for(let f=0;f<%d;++f){ scene.camera.move(0.07,-0.03); r.recalculateScene(); rt.render(r.ctx); if(f>=2) rt.readPixelsAsync(r.ctx,2,host[f-2]); }
+  rt.readPixelsAsync(r.ctx,1,host[%d-2]); rt.readPixelsAsync(r.ctx,0,host[%d-1]);
+  await rt.wait(r.ctx); rt.readPixelsWait(r.ctx);
+  console.log(JSON.stringify({sha: host.map(h=>crypto.createHash('sha256').update(h).digest('hex')), kernel: rt.kernelName(rt.stats(r.ctx).kernelId), build: rt.buildId()}));
+  r.close();
+})().catch(e=>{console.error(e);process.exit(1)});""" % (W, H, B, K, W * H * 4, K, K, K))
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
+    scene = rt.synthetic_scene(300, 361)
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    want = []
+    for f in range(K):
+        scene.camera.move(0.07, -0.03)
+        want.append(hashlib.sha256(oracle.render(scene.pack_params(B), scene.pack_spheres(), sky.faces, W, H)[0].tobytes()).hexdigest())
+    assert got["sha"] == want and got["kernel"] == "bvh_pixels<8>" and len(got["build"]) == 16
