@@ -48,8 +48,50 @@
 //      approach to c, |o-C|^2 = |P-C|^2 - t_c^2 + 2 t_c T <= (D + sqrt(r^2+d))^2 (1 + 2e-6), and here
 //      L <= 2.1 Rg, so sqrt(d) < 0.003 Rg and |o-C| < 1.004 Rg < R: the origin is inside the node
 //      and the test passes on its second term.
+//
+// Shadow rays are walked BACKWARDS under the sign-aware test (reversed_shadow_walk below): from just behind the shaded
+// point P towards the light L, so that everything beyond P -- behind the walk's origin -- is dropped by min(b, 0) at no
+// cost.  The candidates are still evaluated literally with the reference's ray (L, s), s = fl(normalize(P - L)), and the
+// reference uses of that ray only this: `lit` iff the NEAREST literal hit t_min has |L + t_min s - P| < 0.005, else
+// minIntensity (RK:147-165).  Notation: l = |P - L|, Lam = |L| + |P| + l, kappa_f = 2^-16 = 256u (the r^2 (1 + kappa_f) of
+// every record), X = |w - c|^2 + r^2 for the walk's origin w.
+//   A. What may be dropped.  P - L = l e for the exact unit vector e, |s - e| < 4u, so |L + t s - P| >= (t - l) - 7ut; forming
+//      the hit point, the difference and its length adds < u (2t + |L|) and a relative 4u: a literal t >= l + dA,
+//      dA = 0.005001 + 10u (l + |L|), yields diff >= 0.005.  A candidate set that holds every literally accepted sphere with
+//      t < l + dA therefore gives the reference's result: a `lit` t_min is in it and is its minimum; otherwise what is left
+//      is later than l + dA or nothing, and RK:165 returns the same value for "no hit" as for "hit elsewhere".
+//   B. Where the walk starts.  w = fl(P + delta s), delta = 0.0051 + 2^-17 (|P-L|_1 + |L|_1); the walk looks along -s and adds
+//      m = 2^-12 (|P-L|_1 + delta)^2 + 2^-21 (|P-L|_1 + |L|_1)^2 to the tested value (folded into the per-ray q; l1 norms
+//      bound the Euclidean ones, lam = |w - L| <= |P-L|_1 + delta).  w is within eps_o < 6u Lam of the literal ray's line, at
+//      parameter tau_w >= l + delta - 6u Lam.  Take a sphere (c, r) accepted literally with t < l + dA; T_c, rho_c:
+//      parameter and distance of c on / from that line, wc^2 = max(0, r^2 - rho_c^2), d = 24u (|L-c|^2 + r^2) as in step 1.
+//      Then rho_c^2 <= r^2 + d and, following HK:317 operation by operation, T_c - sqrt(wc^2 + d)(1 + u) <= t + 8ut + 4u |L-c|.
+//      Seen from w (primed): rho'_c <= rho_c + eps_o and T'_c = tau_w - T_c +- eps_o.  Either
+//        (1) T'_c > 0: c is ahead of w and rho'_c <= r + e1, e1 = sqrt(d) + eps_o; or
+//        (2) T'_c <= 0: delta - dA >= 59u Lam pays for every term that depends on the ray alone (eps_o, tau_w, 8ut,
+//            4u lam <= 24u Lam), which leaves -T'_c < sqrt(wc^2 + d)(1 + u) + 4u |w-c| and, with rho'_c^2 + wc^2 <=
+//            (r + eps_o)^2 + d, |w - c| < r + e2, e2 = eps_o + sqrt(2d + 16u X): w is inside the sphere up to e2.
+//      Priced from w: |L-c| <= lam + |w-c| gives d <= 48u lam^2 + 48u X (d <= 120u lam^2 + 30u |w-c|^2 + 24u r^2 where
+//      that is tighter).
+//   C. The tests pass.  The walk's test passes when rho'^2 < r^2 (1 + kappa_f) + 2 kappa_h T'^2 + m - 14u X (computed b < 0), or
+//      when |w-c|^2 < r^2 (1 + kappa_f) + m - 14u X (computed b >= 0: T' <= 7.3e-7 |w-c|, so |w-c|^2 <= rho'^2 (1 + 1e-12)).
+//      Leaf, case (1): X <= 2 r^2 + T'^2 (+ e1 terms), so d + 2 eps_o (r + sqrt d) + eps_o^2 + 14u X <=
+//        48u lam^2 + 62u X + 40u r^2 + eps_o^2 / 40u <= [164u r^2] + [62u T'^2] + [48u lam^2 + 2u Lam^2]: under kappa_f r^2,
+//        2 kappa_h T'^2 = 2048u T'^2 and m >= 4096u lam^2 + 2u Lam^2 (Lam <= 2 (|P-L|_1 + |L|_1)).
+//      Leaf, case (2): |w-c|^2 < (r + eps_o)^2 + 2d + 16u X with X < 2 r^2 (1 + 1e-5): 2d + 30u X + 2 eps_o r + eps_o^2 <=
+//        [108u + 60u + 40u] r^2 + [240u lam^2 + 2u Lam^2] -- 208u r^2 under kappa_f r^2 = 256u r^2, the rest under m.
+//      Inner node (C, R = Rg (1 + sigma)), D = |C - c| <= Rg - r: rho'_C <= rho'_c + D and |w-C| <= |w-c| + D, so the node
+//        passes if (Rg + e)^2 <= Rg^2 (1 + 0.0816) + 2 kappa_h T'_C^2 + m - 14u (|w-C|^2 + R^2) with e = e1 or e2 (node centre
+//        behind w, member ahead: |w-C|^2 <= (rho'_c + D)^2 (1 + 2e-6) as in step 3).  Case (2): |w-C| <= Rg + e2 and
+//        sqrt(X) <= 1.42 r + e2, so e2 <= eps_o + 2.4e-3 lam + 3.7e-3 Rg and 2 Rg e2 + e2^2 <= 0.07 Rg^2 + (2.4e-3 lam)^2 / 0.06
+//        + ... = 0.07 Rg^2 + 9.6e-5 lam^2.  Case (1): e1 <= eps_o + 1.69e-3 (lam + sqrt X), sqrt X <= |w-C| + Rg <=
+//        2 Rg + e1 + |T'_C|; 2 Rg * 1.69e-3 |T'_C| <= 1.69e-3 (15.4 Rg^2 + T'_C^2 / 15.4) = 0.026 Rg^2 + 1.1e-4 T'_C^2 (under
+//        2 kappa_h T'_C^2 = 1.22e-4 T'_C^2 less the 14u); 2 Rg * 1.69e-3 lam <= 0.045 Rg^2 + 6.3e-5 lam^2; the rest
+//        6.8e-3 Rg^2 + second-order terms < 0.003 Rg^2: 0.081 Rg^2 + 6.3e-5 lam^2 in all.  m >= 2.44e-4 lam^2 covers both.
+// Forward rays (lam = 0, eps_o = 0, m = 0) are steps 1-3 unchanged.
 // The argument is checked the only way that counts: frames are compared bit for bit with the
-// oracle (tests/test_bvh_gpu.py: golden frames, random scenes over five orders of magnitude).
+// oracle (tests/test_bvh_gpu.py: golden frames, random scenes over five orders of magnitude), and the walk, restated in
+// emulated fp32, against the literal test on rays built to graze (tests/test_hierarchy_walk_cpu.py).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -58,6 +100,11 @@
 #include "rt_filter.h"
 
 #define RT_BVH_KAPPA 6.103515625e-05f   /* kappa_h = 2^-14: inflation of the ray direction in the walk */
+/* the reversed walk of shadow rays (claims A-C of the header) */
+#define RT_BVH_REV_DELTA 0.0051f                    /* the walk starts delta = 0.0051 + 2^-17 (|P-L|_1 + |L|_1) behind P */
+#define RT_BVH_REV_DELTA_REL 7.62939453125e-06f     /* 2^-17 */
+#define RT_BVH_REV_SLACK 2.44140625e-04f            /* 2^-12 |w-L|^2 ... */
+#define RT_BVH_REV_SLACK_ABS 4.76837158203125e-07f  /* ... + 2^-21 (|P-L|_1 + |L|_1)^2 added to the tested discriminant */
 
 // Lanes still walking below which a wave suspends the walk (0: never): a launch argument (launch_bvh_as)
 // with these defaults.  Round-1 kernel (tools/ab.py): C3 3.93 / 3.51 / 3.36 / 3.40 / 3.44 ms and C5 40.7 /
@@ -216,6 +263,28 @@ __device__ __forceinline__ void exact_any_order(v3 center, float r2, int s, v3 o
     }
 }
 
+// The walk of a SHADOW ray under the sign-aware node test runs backwards.  RK:147-165 casts the ray from the light L
+// along s = normalize(P - L) towards the shaded point P and keeps the nearest hit; the result is `lit` only if that hit
+// lies within 0.005 of P.  Spheres beyond P cannot change that (claim A in the header), so the walk need not visit
+// them: it starts just behind P (w = P + delta s) and looks back along -s, where the sign-aware test drops every node
+// behind its origin for free -- the far half of the scene, a fifth of the tests of a shadow ray (C3: 49.7 -> 39.4 per
+// ray, candidates 3.2 -> 2.3).  The candidates are then evaluated as ever, literally, with the ray (L, s).  delta and
+// the additive slack madd of the tested discriminant are derived in the header (claims A-C); l1 norms because they
+// bound the Euclidean ones from above and cost three additions.
+__device__ __forceinline__ void reversed_shadow_walk(bool shadow, v3 L, float light_l1, v3 P, v3 s, v3& wo, v3& wd, float& madd) {
+    const v3 dl = sub(P, L);
+    const float l1 = (__builtin_fabsf(dl.x) + __builtin_fabsf(dl.y)) + __builtin_fabsf(dl.z);
+    const float la = l1 + light_l1;                                         // >= |P - L|, and >= |P| by the triangle inequality
+    const float delta = __builtin_fmaf(la, RT_BVH_REV_DELTA_REL, RT_BVH_REV_DELTA);
+    const float lb = l1 + delta;                                            // >= |w - L|
+    const float slack = __builtin_fmaf(lb * lb, RT_BVH_REV_SLACK, (la * la) * RT_BVH_REV_SLACK_ABS);
+    if (shadow) {
+        wo = V(__builtin_fmaf(delta, s.x, P.x), __builtin_fmaf(delta, s.y, P.y), __builtin_fmaf(delta, s.z, P.z));
+        wd = V(-s.x, -s.y, -s.z);
+        madd = slack;
+    }
+}
+
 // Advances the walk of every lane's ray (o, d).  R/L: node records and links (LDS or global),
 // n: node count, geo: exact {c, r*r}.  slot: this lane's candidate column ([k*64]).
 // i: the lane's position in the node array, in and out: 0 starts a ray (the caller then also sets
@@ -226,18 +295,20 @@ __device__ __forceinline__ void exact_any_order(v3 center, float r2, int s, v3 o
 template <bool SGN, bool NLDS, int CAP>
 __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
                                           const float4* __restrict__ geo, uint32_t* slot, unsigned long long* best,
-                                          uint32_t& i, v3 o, v3 d, float& nearest, int& idx
+                                          uint32_t& i, v3 o, v3 d, v3 wo, v3 wd, float madd, float& nearest, int& idx
 #ifdef RT_BVH_COUNT
                                           , uint32_t& steps_acc
 #endif
                                           ) {
-    const float a = dot(d, d);           // HK:308
+    // (o, d): the ray the candidates are evaluated with, literally.  (wo, wd, madd): the ray the WALK selects them
+    // with -- the same ray, madd = 0, except for shadow rays under the sign-aware test (reversed_shadow_walk).
+    const float a = dot(wd, wd);         // HK:308
     const float inv = __builtin_amdgcn_rsqf(a) * (1.0f + RT_BVH_KAPPA);
-    const v3 h = V(d.x * inv, d.y * inv, d.z * inv);
-    const v3 os = V(o.x * RT_FILTER_SCALE, o.y * RT_FILTER_SCALE, o.z * RT_FILTER_SCALE);   // exact
+    const v3 h = V(wd.x * inv, wd.y * inv, wd.z * inv);
+    const v3 os = V(wo.x * RT_FILTER_SCALE, wo.y * RT_FILTER_SCALE, wo.z * RT_FILTER_SCALE);   // exact
     const v3 m = V(-2.0f * os.x, -2.0f * os.y, -2.0f * os.z);
     const float p = dot(h, os);
-    const float q = dot(os, os) * (1.0f - RT_FILTER_EPS);
+    const float q = __builtin_fmaf(-madd, RT_FILTER_SCALE2, dot(os, os) * (1.0f - RT_FILTER_EPS));
     // Sign-aware test on LDS nodes: min(b, 0) comes free as the `clamp` of the FMA that completes -b,
     // once everything is rescaled so that |b| < 1: -b * 2^-62 (|b| < 2^61 inside the filter's validity
     // range), and with it the squared quantities * 2^-124 -- powers of two, so every mantissa, hence every
@@ -430,6 +501,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
     __syncthreads();
 
     const Scene sc = unpack_scene(A);
+    const float light_l1 = (__builtin_fabsf(sc.lightPos.x) + __builtin_fabsf(sc.lightPos.y)) + __builtin_fabsf(sc.lightPos.z);
     const uint32_t tiles_x = (A.W + 7u) / 8u;
     const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
     uint32_t cur = 0, end = 0;                                   // wave-uniform chunk cursor
@@ -522,12 +594,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
         bool finished = active && sc.bounces == 0u;
         bool missed = false;
         const bool walking = node != n;
+        // the ray the walk selects candidates with (recomputed per trip from the path state: a suspended walk resumes
+        // with the same values)
+        v3 wo = ro, wd = shadow ? sdir : rd;
+        float madd = 0.0f;
+        if (SGN) reversed_shadow_walk(shadow, sc.lightPos, light_l1, ro, sdir, wo, wd, madd);
+        else if (shadow) wo = sc.lightPos;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
-        trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx, nrays);
+        trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx, nrays);
         if (walking && node == n) {
 #else
-        trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, t, idx);
+        trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx);
         if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
 #endif

@@ -45,8 +45,8 @@ def hierarchy(rec):
     return out, link, m
 
 
-def walk(out, link, m, o, d, sgn):
-    """trace_bvh's candidate selection (one lane)."""
+def walk(out, link, m, o, d, sgn, madd=0.0):
+    """trace_bvh's candidate selection (one lane); madd: the additive slack of a reversed shadow walk."""
     o = o.astype(f32); d = d.astype(f32)
     a = f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2]))
     inv = f32(f32(1.0 / np.sqrt(np.float64(a))) * f32(1.0 + KAPPA_H))          # v_rsq_f32 to ~1 ulp
@@ -55,6 +55,7 @@ def walk(out, link, m, o, d, sgn):
     mm = (f32(-2.0) * os_).astype(f32)
     p = f32(f32(f32(h[0] * os_[0]) + f32(h[1] * os_[1])) + f32(h[2] * os_[2]))
     q = f32(f32(f32(f32(os_[0] * os_[0]) + f32(os_[1] * os_[1])) + f32(os_[2] * os_[2])) * f32(1.0 - EPS))
+    q = fma(-f32(madd), f32(S2), q)
     cands, tests, j = [], 0, 0
     with np.errstate(over="ignore", invalid="ignore"):
         while j != m:
@@ -71,7 +72,7 @@ def walk(out, link, m, o, d, sgn):
     return set(cands), tests
 
 
-def literal_hits(rec, o, d):
+def literal_hits(rec, o, d, want_t=False):
     """HK:308-318 for every sphere, fp32, the oracle's operation order."""
     o = o.astype(f32); d = d.astype(f32)
     c = rec[:, 0:3]
@@ -87,6 +88,8 @@ def literal_hits(rec, o, d):
     with np.errstate(invalid="ignore", divide="ignore"):
         t = ((-b - np.sqrt(disc).astype(f32)).astype(f32) / f32(f32(2.0) * a)).astype(f32)
         hit = (disc > 0) & (t > f32(0.001)) & (t < f32(9999.0))
+    if want_t:
+        return hit, t
     return set(np.nonzero(hit)[0].tolist())
 
 
@@ -165,3 +168,108 @@ def test_small_spheres_far_from_every_origin():
         spheres = [rt.Sphere(p, radius * float(rng.uniform(0.5, 2.0)), [1, 1, 1]) for p in pos]
         hits, _, _ = run_case(spheres, [0.0, 0.0, 0.0], [0.1 * dist, 0.8 * dist, -0.2 * dist], seed=3, count=300)
         assert hits > 0
+
+
+# ---- shadow rays: the walk runs backwards from just behind the shaded point (rt_bvh.hip: reversed_shadow_walk) ----------
+REV_DELTA, REV_DELTA_REL, REV_SLACK, REV_SLACK_ABS = 0.0051, 2.0 ** -17, 2.0 ** -12, 2.0 ** -21
+
+
+def length32(v):
+    return f32(np.sqrt(f32(f32(f32(v[0] * v[0]) + f32(v[1] * v[1])) + f32(v[2] * v[2]))))
+
+
+def reversed_walk_ray(L, P, s):
+    """The kernel's statements, fp32: the walk's origin, direction and additive slack for the shadow ray (L, s) towards P."""
+    dl = (P - L).astype(f32)
+    l1 = f32(f32(abs(dl[0]) + abs(dl[1])) + abs(dl[2]))
+    la = f32(l1 + f32(f32(abs(L[0]) + abs(L[1])) + abs(L[2])))
+    delta = fma(la, f32(REV_DELTA_REL), f32(REV_DELTA))
+    lb = f32(l1 + delta)
+    madd = fma(f32(lb * lb), f32(REV_SLACK), f32(f32(la * la) * f32(REV_SLACK_ABS)))
+    wo = np.array([fma(delta, s[k], P[k]) for k in range(3)], f32)
+    return wo, (-s).astype(f32), madd
+
+
+def lit(hit, t, L, s, P):
+    """RK:155-159 in fp32: is the nearest of `hit` within 0.005 of P?"""
+    if not hit.any():
+        return False
+    tm = t[hit].min()
+    dv = ((L + (tm * s).astype(f32)).astype(f32) - P).astype(f32)
+    return bool(length32(dv) < f32(0.005))
+
+
+def shaded_points(rec, L, rng, count):
+    """Points a shadow ray is cast towards: on sphere surfaces (lit and far sides), and along rays from the light that graze
+    a sphere, at depths around its entry and exit points -- where the reversed walk's origin lands on, in and just outside
+    spheres."""
+    c = rec[:, 0:3].astype(np.float64); r = np.abs(rec[:, 7].astype(np.float64))
+    L = np.array(L, float)
+    for k in range(count):
+        s = int(rng.integers(0, len(r)))
+        if k % 3 == 0:
+            v = rng.normal(size=3); v /= np.linalg.norm(v)
+            P = c[s] + v * r[s] * (1.0 + rng.choice([0.0, 1e-7, -1e-7, 1e-4]))
+        else:
+            to = c[s] - L; dist = np.linalg.norm(to)
+            if dist < 1e-9:
+                continue
+            w = rng.normal(size=3); w -= w @ to / dist ** 2 * to; w /= max(np.linalg.norm(w), 1e-30)
+            dirn = to + w * r[s] * rng.choice([0.0, 0.5, 0.9, 0.999, 0.9999, 1.0, 1.0001, 1.001])
+            dirn /= np.linalg.norm(dirn)
+            tc = dirn @ to
+            half = np.sqrt(max(0.0, r[s] ** 2 - max(0.0, to @ to - tc * tc)))
+            depth = tc + rng.choice([-half, 0.0, half, -half - 0.004, -half + 0.004, half + 0.004, -half - 0.0055, r[s], -r[s], 3 * r[s]]) \
+                + rng.choice([0.0, 1e-4, -1e-4, 1e-3])
+            P = L + max(depth, 1e-3) * dirn
+        yield P.astype(f32)
+
+
+def run_shadow_case(spheres, light, seed, count):
+    rec = np.ascontiguousarray(rt.SceneRaytracing().createScene(spheres).pack_spheres(), dtype=f32).reshape(-1, 8)
+    out, link, m = hierarchy(rec)
+    L = np.array(light, f32)
+    n_lit = fwd = rev = 0
+    for P in shaded_points(rec, L, np.random.default_rng(seed), count):
+        dl = (P - L).astype(f32)
+        s = (dl / length32(dl)).astype(f32)                                  # RK:147
+        if not np.isfinite(s).all():
+            continue
+        hit, t = literal_hits(rec, L, s, want_t=True)
+        wo, wd, madd = reversed_walk_ray(L, P, s)
+        cands, tests = walk(out, link, m, wo, wd, True, madd)
+        keep = np.zeros_like(hit); keep[list(cands)] = True
+        want = lit(hit, t, L, s, P)
+        assert lit(hit & keep, t, L, s, P) == want, ("shadow result changed", P, L)
+        # the stronger statement the header proves (claim B): nothing accepted before l + dA is lost
+        ell = np.linalg.norm((P - L).astype(np.float64))
+        d_a = 0.005001 + 10 * 2.0 ** -24 * (ell + np.linalg.norm(L.astype(np.float64)))
+        near = set(np.nonzero(hit & (t.astype(np.float64) < ell + d_a))[0].tolist())
+        assert near <= cands, ("lost", sorted(near - cands), P, L)
+        n_lit += want; rev += tests; fwd += walk(out, link, m, L, s, True)[1]
+    return n_lit, fwd, rev
+
+
+def test_reversed_shadow_walk_baseline_scene():
+    n_lit, fwd, rev = run_shadow_case(synthetic_spheres(300, 5), [0, 5, 0], seed=1, count=900)
+    assert n_lit > 50                     # both results occur
+    assert rev < 0.9 * fwd                # and the reversed walk is the shorter one
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_reversed_shadow_walk_scales_and_offsets(seed):
+    """Only scenes the host plans the sign-aware test for (reach < 342) walk shadow rays backwards."""
+    rng = np.random.default_rng(200 + seed)
+    scale = float(10 ** rng.uniform(-2, 1.7))
+    off = float(rng.choice([0.0, 10.0, 100.0])) * np.array([1.0, 0.5, -0.25])
+    ratio = float(10 ** rng.uniform(0, 2.5))
+    n = int(rng.choice([17, 64, 200]))
+    spheres = [rt.Sphere(off + rng.normal(size=3) * scale, scale * 0.25 / ratio * float(10 ** rng.uniform(0, np.log10(ratio))),
+                         [1, 1, 1]) for _ in range(n)]
+    if seed % 2:
+        R = scale * float(10 ** rng.uniform(0.5, 1.0))
+        spheres.append(rt.Sphere(off + np.array([0, -R - scale, 0]), R, [1, 1, 1]))
+    light = off + np.array([0.3 * scale, 2.5 * scale, 0.5 * scale])
+    if seed == 4:
+        light = np.array(spheres[3].center, float)            # the light inside a sphere
+    run_shadow_case(spheres, light, seed, count=400)
