@@ -176,6 +176,7 @@ int rt_create(int device, rt_ctx** out) {
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return fail(RT_ERR_HIP, "rt_create: out of host memory");
     c->device = device;
+    c->wave_slots = (uint32_t)prop.multiProcessorCount * 16u;      // 4 SIMDs x 4 waves of the triangle kernel (launch_tri: OCC)
     hipError_t err;
     err = hipSuccess;
     for (int k = 0; k < kStreams && err == hipSuccess; ++k) err = hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking);
@@ -222,6 +223,7 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
     for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex, &c->d_corners}) (void)hipFree(b->p);
+    for (int k = 0; k < kStreams; ++k) { (void)hipFree(c->d_tile_cost[k].p); (void)hipFree(c->d_tile_order[k].p); }
     for (int v = 0; v < kVersions; ++v)
         for (rt_ctx::DevBuf* b : {&c->d_nodes[v], &c->d_blas[v], &c->d_blas_lookup[v]}) (void)hipFree(b->p);
     (void)hipFree(c->d_rays);
@@ -772,6 +774,26 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         c->ver_gen[v] = c->inst.gen;
         ++c->stats.instance_uploads;
     }
+    // tile order of the triangle kernel: only for frames on the library's own streams (each has its set of buffers)
+    int order_set = -1;
+    const uint32_t order_n = ((c->W + 7u) / 8u) * fa.n_local_tiles;
+    // ... and only for a caller that waits after each frame (the reference's loop): with frames in flight the tiles of
+    // the next frame fill the slots a long tile leaves idle anyway, and row-major order keeps neighbours in one L2
+    if (tri && c->kernel != RT_KERNEL_HEATMAP && order_n >= kOrderMinTiles && !hint) {
+        for (int k = 0; k < kStreams; ++k) if (s == c->streams[k]) order_set = k;
+        if (order_set >= 0 && c->d_tile_cost[order_set].cap < (size_t)order_n * 4u) {
+            // only frames on this stream use the set: wait for them, not for the batch (no slot bookkeeping involved)
+            RT_HIP(hipStreamSynchronize(s));
+            for (rt_ctx::DevBuf* b : {&c->d_tile_cost[order_set], &c->d_tile_order[order_set]}) {
+                (void)hipFree(b->p);
+                b->p = nullptr; b->cap = 0;
+                RT_HIP(hipMalloc(&b->p, (size_t)order_n * 4u + 4u));       // the list carries a header word
+                b->cap = (size_t)order_n * 4u;
+            }
+            RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));   // tiles ADD their times
+            c->order_tiles[order_set] = 0;
+        }
+    }
     if (tri && !c->corners_valid) {
         // the compact corner array follows the triangles and the lookup table; both writes drained, nothing reads it now
         const uint32_t n_slots = (uint32_t)(c->d_tri_lookup.used / 4u);
@@ -800,17 +822,48 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.n_tri_lookup = (uint32_t)(c->d_tri_lookup.used / 4u);
         ts.n_blas_lookup = c->inst.lookup_on ? (uint32_t)c->inst.lookup.size() : (uint32_t)(c->d_blas_lookup[v].used / 4u);
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
+        ts.tile_order = nullptr; ts.tile_cost = nullptr;
+#ifdef RT355_DEV_EXPORTS
+        if (order_set >= 0 && getenv("RT355_KEEP_TILE_COST")) RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));
+#endif
+        if (order_set >= 0) {
+            ts.tile_cost = static_cast<uint32_t*>(c->d_tile_cost[order_set].p);
+            if (c->order_tiles[order_set] == order_n) ts.tile_order = static_cast<const uint32_t*>(c->d_tile_order[order_set].p);
+        }
         RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
     } else {
         if (use_bvh) RT_HIP(rt_launch_bvh(fa, s));
         else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
+#ifdef RT355_DEV_EXPORTS
+    if (order_set >= 0 && getenv("RT355_KEEP_TILE_COST")) {      // tools/tile_cost_probe.py reads the times of whole tiles in index order
+        c->order_tiles[order_set] = 0;
+        order_set = -1;
+    }
+#endif
+    if (order_set >= 0) {
+        // after the frame's event: rt_wait does not wait for it, the stream's next frame does
+        RT_HIP(rt_launch_order_tiles(static_cast<uint32_t*>(c->d_tile_cost[order_set].p),
+                                     static_cast<uint32_t*>(c->d_tile_order[order_set].p), order_n, c->wave_slots, s));
+        c->order_tiles[order_set] = order_n;
+    }
     c->stats.kernel_id = (uint32_t)g_rt_kernel_id;
     c->stats.grid_share = fa.grid_share;
     c->in_flight = slot + 1;
     return RT_OK;
 }
+
+#ifdef RT355_DEV_EXPORTS
+// development builds only (tools/tile_cost_probe.py): the per-tile times of the last frame rendered on stream `set`
+__attribute__((visibility("default"))) int rt_debug_tile_cost(rt_ctx* c, int set, uint32_t* dst, uint32_t cap) {
+    if (!c || set < 0 || set >= kStreams || !c->d_tile_cost[set].p) return -1;
+    const uint32_t n = std::min(cap, (uint32_t)(c->d_tile_cost[set].cap / 4u));
+    if (hipStreamSynchronize(c->streams[set]) != hipSuccess) return -1;
+    if (hipMemcpy(dst, c->d_tile_cost[set].p, (size_t)n * 4u, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
 
 int rt_render(rt_ctx* c) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_render: ctx is NULL");

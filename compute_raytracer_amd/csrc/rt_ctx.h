@@ -36,6 +36,7 @@ constexpr int kStreams = 4;
 constexpr int kVersions = 4;         // versions of the per-frame instance buffers (>= kStreams)
 constexpr uint32_t kHeadNodes = 31u; // TLAS nodes (2 M - 1 for M <= 16 instances) that travel with a frame
 constexpr uint32_t kInstMax = 16u;   // instances whose records travel with a frame
+constexpr uint32_t kOrderMinTiles = 4096u;   // frames of fewer tiles than the chip has wave slots start all of them at once: no order to choose
 constexpr size_t kCounterBytes = (size_t)RT_RAY_COUNTERS * RT_RAY_COUNTER_STRIDE;   // partial ray counters of one frame
 constexpr size_t kCtrlBytes = kCounterBytes + 32u;                                   // + the 32-byte control block
 
@@ -103,6 +104,11 @@ struct rt_ctx {
     DevBuf d_tri, d_tri_lookup, d_tex;
     DevBuf d_corners;                            // 48 B per lookup slot: the corners hitTriangle reads, in lookup order (tri_corners)
     bool corners_valid = false;                  // ... built since the last rt_write_triangles / rt_write_tri_lookup
+    // Tile order of the triangle kernel (rt_triangles.hip: order_tiles), one set per stream of rt_render: the time every
+    // tile of the stream's last frame took, and the longest-first permutation made of it for the stream's next frame.
+    DevBuf d_tile_cost[kStreams], d_tile_order[kStreams];
+    uint32_t wave_slots = 4096;                      // waves of the triangle kernel the device holds at once
+    uint32_t order_tiles[kStreams] = {0, 0, 0, 0};   // tile count d_tile_order[k] is a permutation of (0: none yet)
     // The buffers the reference rewrites before every frame (RR:169-192: BLAS records, BLAS lookup, the TLAS nodes at
     // the head of the node buffer) exist in kVersions versions: a frame in flight keeps reading the version it was
     // enqueued with while the host already writes the next state (rt_api.hip: apply_instances).

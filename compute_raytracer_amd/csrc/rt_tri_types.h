@@ -11,7 +11,13 @@ struct RtTriScene {
     const float* blas_lookup;  // [n_blas_lookup] f32 indices
     const uint8_t* tex;        // meshTex, rgba8unorm
     uint32_t n_nodes, n_blas, n_tri, n_tri_lookup, n_blas_lookup, tex_w, tex_h;
+    // Work list (rt_triangles.hip: order_tiles): tile_order[0] tiles are rendered as four quarters, tile_order[1...] is the
+    // order of the tiles (null: every tile whole, in index order); every workgroup adds the time it took to
+    // tile_cost[tile] (null: nowhere), from which the list of the next frame on this stream is made.
+    const uint32_t* tile_order;
+    uint32_t* tile_cost;
 };
 
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);
+hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s);
 hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* lookup, uint32_t n_slots, uint32_t n_tri, hipStream_t s);

@@ -294,10 +294,24 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     const TriLds L = stage_head<WAVES>(T, s_nodes, s_blas);
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * (8u * WAVES) + wave * 8u + (lane & 7u);
-    const uint32_t row = lane >> 3;
-    const uint32_t y = (A.tile_first + blockIdx.y * A.tile_step) * 8u + row;
-    if (x >= A.W || y >= A.H) return;
+    // one workgroup per tile, or per quarter of a tile the previous frame on this stream found long (order_tiles)
+    const uint64_t clk0 = wall_clock64();
+    const uint32_t groups_x = (A.W + 8u * WAVES - 1u) / (8u * WAVES);
+    const uint32_t n_tiles = groups_x * A.n_local_tiles;
+    uint32_t tile = blockIdx.x, part = 4u;                                  // part 0-3: a 4x4 quarter; 4: the whole tile
+    if (T.tile_order) {
+        const uint32_t split = T.tile_order[0];
+        if (blockIdx.x < 4u * split) { tile = T.tile_order[1u + (blockIdx.x >> 2)]; part = blockIdx.x & 3u; }
+        else if (blockIdx.x - 3u * split < n_tiles) tile = T.tile_order[1u + blockIdx.x - 3u * split];
+        else return;                                                        // the grid is sized for the most quarters there can be
+    }
+    const uint32_t by = tile / groups_x, bx = tile - by * groups_x;
+    if (part != 4u && lane >= 16u) return;
+    const uint32_t px = part == 4u ? (lane & 7u) : 4u * (part & 1u) + (lane & 3u);
+    const uint32_t row = part == 4u ? (lane >> 3) : 4u * (part >> 1) + (lane >> 2);
+    const uint32_t x = bx * (8u * WAVES) + wave * 8u + px;
+    const uint32_t y = (A.tile_first + by * A.tile_step) * 8u + row;
+    if (x >= A.W || y >= A.H) return;          // thread 0 leaves here only with its whole tile or quarter: its pixel is their first
 
     const Scene sc = unpack_scene(A);
     uint32_t nrays = 0;
@@ -336,12 +350,65 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
         affect = affect / 2.0f;                                                      // RK:139
         sum = next;                                                                  // RK:140
     }
-    const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;
+    const uint32_t opix = (by * 8u + row) * A.W + x;
     // the fog colour is the sky along the primary ray (RK:93-96): its direction is formed again here rather than
     // carried through both traversals
     reinterpret_cast<uint32_t*>(A.out)[opix] =
         compose_pixel_sky(scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, primary_dir(A, sc, x, y))), color, dist);   // RK:91-98
     count_rays(A.rays, nrays);
+    if (T.tile_cost && threadIdx.x == 0u) atomicAdd(&T.tile_cost[tile], (uint32_t)(wall_clock64() - clk0));   // 10 ns ticks; quarters add up
+}
+
+// ---- the order of the next frame's tiles ------------------------------------------------------------------
+// The frame is a grid of independent tiles, one wave each, whose costs differ by more than an order of magnitude (a sky tile:
+// one ray per pixel; a tile between two mirrors: 2 x bounces dependent traversals by 64 diverging lanes), and the hardware
+// starts them in index order.  Measured with the kernel's own clock (tools/tile_cost_probe.py, profiles/r03/tile_cost.log):
+// mean tile 21 us, one in a hundred 156 us, the longest 498 us -- and the 1344x846 frame rendered on its own (the
+// reference's await-each-frame loop) took 504 us: a frame is as long as its longest tile, however empty the chip.  So
+//   * every tile leaves the time it took (tile_cost; quarters add theirs up);
+//   * one workgroup turns the costs into the NEXT frame's work list on the same stream: tiles longest first (a counting sort
+//     over quarter-octave classes), and the tiles longer than half the frame's throughput time -- sum of all costs / wave
+//     slots / 2 --, at most one in sixteen and 1024 (a quarter-wave for every wave slot of the chip), as four 4x4 quarters each: a quarter of the lanes diverge a quarter as much, and
+//     the frame's longest wave shrinks accordingly.  order[0] = number of split tiles, order[1...] = the permutation.
+// The picture does not depend on any of it: a pixel is rendered by the same code whatever its turn and company; any
+// array of costs yields a permutation and a split count within the grid's bound.
+__global__ __launch_bounds__(1024) void order_tiles(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, uint32_t wave_slots) {
+    __shared__ uint32_t bin[128];
+    __shared__ unsigned long long total;
+    if (threadIdx.x < 128u) bin[threadIdx.x] = 0u;
+    if (threadIdx.x == 0u) total = 0ull;
+    __syncthreads();
+    auto cls = [](uint32_t c) -> uint32_t {        // quarter-octave class of a tick count: 0 ... 123, monotone
+        if (c < 4u) return c;
+        const uint32_t e = 31u - (uint32_t)__clz(c);
+        return 4u * e + ((c >> (e - 2u)) & 3u) - 4u;
+    };
+    unsigned long long mine = 0ull;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) { const uint32_t c = cost[i]; mine += c; atomicAdd(&bin[cls(c)], 1u); }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0u) {                       // exclusive prefix over the classes, longest class first
+        const unsigned long long thr = total / (2ull * (wave_slots ? wave_slots : 1u));
+        const uint32_t kt = cls(thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr);
+        const unsigned long long whole = 4ull * thr;           // twice the throughput time
+        const uint32_t kw = cls(whole > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)whole);
+        uint32_t acc = 0u, split = 0u;
+        bool pays = false;                         // some tile takes more than twice the throughput time: the frame waits for it.
+        for (int k = 127; k >= 0; --k) {           // (Otherwise quarters only add waves: 4K, 0.77 -> 0.81 ms with them.)
+            const uint32_t v = bin[k];
+            bin[k] = acc; acc += v;
+            if (k > (int)kt) split = acc;          // tiles of the classes above the threshold's: all longer than it
+            if (k > (int)kw && v) pays = true;
+        }
+        if (!pays) split = 0u;
+        const uint32_t most = n / 16u < 1024u ? n / 16u : 1024u;      // rt_tri_max_split
+        order[0] = split < most ? split : most;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
+        order[1u + atomicAdd(&bin[cls(cost[i])], 1u)] = i;
+        cost[i] = 0u;                              // the next frame adds its times up from zero
+    }
 }
 
 // ---- kernel: the heatmap twin (HK:63-83) ------------------------------------------------------------
@@ -402,10 +469,18 @@ hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* loo
 // 0.792 / 0.883 ms per 4K frame in flight; profiles/r02/tri_waves.log).
 template <typename STK, int OCC, int WAVES = 1>
 static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
-    dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
+    const dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
+    const uint32_t n_tiles = grid.x * grid.y;       // trace_triangles decodes the tile itself; with a work list: room for the quarters
+    const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) : n_tiles, 1, 1);   // order_tiles: at most that many tiles in quarters
     if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK>), grid, dim3(64 * WAVES), 0, s, a, t);
-    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true>), grid, dim3(64 * WAVES), 0, s, a, t);
-    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false>), grid, dim3(64 * WAVES), 0, s, a, t);
+    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true>), line, dim3(64 * WAVES), 0, s, a, t);
+    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false>), line, dim3(64 * WAVES), 0, s, a, t);
+}
+
+hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(rtk::order_tiles, dim3(1), dim3(1024), 0, s, cost, order, n_tiles, wave_slots);
+    return hipGetLastError();
 }
 
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {

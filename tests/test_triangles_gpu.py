@@ -185,3 +185,40 @@ def test_large_instance_sets_and_whole_buffer_node_writes(oracle):
         assert np.array_equal(r.read_pixels(), ref)
     finally:
         r.close()
+
+
+def test_tile_order_does_not_change_the_picture(oracle):
+    """From 4096 tiles on the triangle kernel starts a frame's tiles longest-first, in the order the previous frame on the
+    same stream suggests (rt_triangles.hip: order_tiles).  1024 x 516 = 8320 tiles, ragged last row; the camera walks and
+    the models spin, so every frame is rendered in an order made for another picture: ten frames one at a time (each of
+    the four streams comes round at least twice), then six in flight, each against the oracle."""
+    W, H, B = 1024, 516, 3
+    scene, mat = triangle_scene(seed=21, n_models=3)
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+    try:
+        for frame in range(10):
+            scene.update(0.2)
+            scene.camera.move(0.08, -0.03)
+            r.render()
+            img = r.read_pixels()
+            ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
+            assert np.array_equal(img, ref), (frame, diff_stats(img, ref))
+            assert r.stats()["rays"] == rays
+        want, host = [], r.host_frames(6)
+        for frame in range(6):
+            scene.update(0.2)
+            scene.camera.move(-0.05, 0.04)
+            r.recalculateScene()
+            r.enqueue()
+            if frame >= 2:
+                r.read_pixels_async(2, host[frame - 2])
+            want.append(oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)[0])
+        r.read_pixels_async(1, host[4])
+        r.read_pixels_async(0, host[5])
+        r.wait()
+        r.read_pixels_wait()
+        for frame in range(6):
+            assert np.array_equal(host[frame].reshape(H, W, 4), want[frame].reshape(H, W, 4)), frame
+    finally:
+        r.close()
