@@ -10,7 +10,9 @@ if "--build" in sys.argv:
     flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -Wall -Wno-unused-function -ffp-contract=off".split()
     os.makedirs(os.path.dirname(DEV), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-DRT355_DEV_EXPORTS", "-DRT355_BUILD_ID=\"dev\"", "-c", os.path.join(csrc, "rt_api.hip"), "-o", "/tmp/rt_api_dev.o"], check=True)
-    objs = [os.path.join(csrc, o) for o in ("rt_kernels.o", "rt_bvh.o", "rt_triangles.o", "rt_assemble.o", "rt_comm.o")]
+    # the same development library serves tools/knob_ab.py: rt_bvh.hip with its environment knobs (RT355_BVH_TAIL, _BLOCKS, _LDS_PAD)
+    subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-fno-slp-vectorize", "-DRT_BVH_DEV_ENV", "-c", os.path.join(csrc, "rt_bvh.hip"), "-o", "/tmp/rt_bvh_dev.o"], check=True)
+    objs = [os.path.join(csrc, o) for o in ("rt_kernels.o", "rt_triangles.o", "rt_assemble.o", "rt_comm.o")] + ["/tmp/rt_bvh_dev.o"]
     subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", DEV, "/tmp/rt_api_dev.o"] + objs + ["-L/opt/rocm/lib", "-lrccl"], check=True)
     print("built", DEV)
     sys.exit(0)
