@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void bvh_refit(float4* __restrict__ rec, const
     const double Cd[3] = {(double)C[0], (double)C[1], (double)C[2]};   // the radius is taken about THAT point
     double unused[3];
     double R = radius_at(Cd, unused);
-    R *= 1.04;
+    R *= RT_BVH_SIGMA;
     const double c2 = Cd[0] * Cd[0] + Cd[1] * Cd[1] + Cd[2] * Cd[2];
     const double k = c2 * (1.0 - (double)RT_FILTER_EPS) - R * R * (1.0 + (double)RT_FILTER_KAPPA);
     if (lane == 0)

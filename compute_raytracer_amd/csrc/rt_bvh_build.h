@@ -14,6 +14,9 @@
 #define RT_FILTER_SCALE 1099511627776.0f
 #define RT_FILTER_SCALE2 1208925819614629174706176.0f
 #endif
+#ifndef RT_BVH_SIGMA
+#define RT_BVH_SIGMA 1.04   /* node radius = bound of the members x this: the slack of the node test's proof (rt_bvh.hip, header) */
+#endif
 
 // ---- host: hierarchy build ---------------------------------------------------------------------------
 namespace {
@@ -149,7 +152,7 @@ struct Builder {
         const double Cd[3] = {C[0], C[1], C[2]};                       // the radius is taken about THAT point
         uint32_t unused = 0;
         double R = radius_at(Cd, unused);
-        R *= 1.04;            // sigma, see the header
+        R *= RT_BVH_SIGMA;            // sigma, see the header
         const double c2 = (double)C[0] * C[0] + (double)C[1] * C[1] + (double)C[2] * C[2];
         const double k = c2 * (1.0 - (double)RT_FILTER_EPS) - R * R * (1.0 + (double)RT_FILTER_KAPPA);
         out[0] = C[0] * RT_FILTER_SCALE; out[1] = C[1] * RT_FILTER_SCALE; out[2] = C[2] * RT_FILTER_SCALE;

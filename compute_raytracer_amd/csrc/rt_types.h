@@ -16,6 +16,11 @@
 #define RT_FILTER_SCALE 1099511627776.0f                 // 2^40
 #define RT_FILTER_SCALE2 1208925819614629174706176.0f    // 2^80
 #define RT_FILTER_UNSCALE 9.094947017729282379150390625e-13f   // 2^-40
+// Inner nodes of the sphere hierarchy: stored radius = bound of the members x this (host build rt_bvh_build.h, device
+// refit rt_bvh.hip: bvh_refit) -- the slack the node test's proof needs (rt_bvh.hip, header).
+#ifndef RT_BVH_SIGMA
+#define RT_BVH_SIGMA 1.04
+#endif
 
 // The ray counter of a frame is RT_RAY_COUNTERS partial sums, RT_RAY_COUNTER_STRIDE bytes apart
 // (rt_device.h: count_rays); the host adds them.
