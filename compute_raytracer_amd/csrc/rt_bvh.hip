@@ -423,8 +423,13 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
         if (RT_BVH_COUNT == 8) g_steps += (!leaf && lk != j) ? 1u : 0u;                // inner nodes tested (lane; the sentinel links to itself)
 #endif
         if (leaf && pass) {
-            *(lds_u32_w)(uintptr_t)wa = lk;
-            wa += 256u;
+            if (NLDS) {   // the store and the advance in place: the compiler forms the new address in a second register and moves it back
+                *(lds_u32_w)(uintptr_t)wa = lk;
+                asm("v_add_u32_e32 %0, 0x100, %0" : "+v"(wa));
+            } else {
+                *(lds_u32_w)(uintptr_t)wa = lk;
+                wa += 256u;
+            }
         }
         return (leaf || pass) ? j + 4u : lk;     // staged links already carry the LDS base
     };
