@@ -435,11 +435,12 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
     };
     const uint32_t jn = 4u * n + l0;
     uint32_t j = 4u * i + l0;
+    // Loop control in the scalar unit, one exit test per trip: the wave leaves when no lane walks any more, or -- once
+    // some lane has finished -- when fewer than `tail` still do (`tail` >= 1 covers the first case whenever the loop was
+    // entered; tail == 0, "never suspend", leaves through the loop condition).
     const uint64_t walking0 = __ballot(j != jn);
-    for (;;) {
-        const uint64_t walking = __ballot(j != jn);
-        if (walking == 0ull) break;
-        if (walking != walking0 && (uint32_t)(__builtin_popcount((uint32_t)walking) + __builtin_popcount((uint32_t)(walking >> 32))) < tail) break;
+    uint64_t walking = walking0;
+    while (walking != 0ull) {
 #ifdef RT_BVH_COUNT   // development statistics: 1 = wave iterations, 2 = lane tests (reported as "rays")
         if (RT_BVH_COUNT == 1) g_steps += (threadIdx.x & 63u) == 0u ? 2u : 0u;
         if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
@@ -451,7 +452,9 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
         j = step(j);
         j = step(j);
         j = step(j);
-        if (__ballot(wa >= wa0 + 256u * (uint32_t)(CAP - 3)) != 0ull) drain();      // room for the four entries of the next trip
+        if (__builtin_expect(__ballot(wa >= wa0 + 256u * (uint32_t)(CAP - 3)) != 0ull, 0)) drain();      // room for the four entries of the next trip
+        walking = __ballot(j != jn);
+        if (walking != walking0 && (uint32_t)__builtin_popcountll(walking) < tail) break;
     }
     drain();
     i = (j - l0) >> 2;
