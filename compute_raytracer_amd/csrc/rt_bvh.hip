@@ -380,10 +380,11 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
         wa = wa0;
     };
 
-    // The walk's state is j = 4 * node index (+ the LDS address of the link array when the nodes
-    // are staged in LDS): the address of the node's link, so that read needs no address
-    // arithmetic, the record's address is one v_lshl_add, and the links themselves are stored in
-    // this unit.  Node n is a sentinel that never passes and links to itself: a lane that is done
+    // The walk's state j is an address.  Nodes staged in LDS: the LDS address of the node's RECORD, 16 x node index + 4 x
+    // (the address of the link array); its link sits at j / 4 (bvh_lds_l0) and inner links are stored in this unit, so
+    // between the compare that decides a step and the record load of the next there is ONE instruction, the select --
+    // the shift that forms the link's address hangs off the side (round 3; before, the state was the link's address and
+    // the shift sat in that chain).  Nodes in global memory: j = 4 x node index, the record at 4 j.  Node n is a sentinel that never passes and links to itself: a lane that is done
     // (or has no ray) idles on it without an exec-mask test per step; the wave leaves the loop
     // when every lane sits there.  Four steps per trip: the loop's own compares and branches are not
     // free on a pipe that is priced per opcode (C3 with frames in flight: 2, 3, 4 steps per trip = 2.22,
@@ -396,8 +397,8 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
         uint32_t lk;
         float4 g;
         if (NLDS) {
-            lk = *(lds_u32)(uintptr_t)j;
-            const f4v gv = *(lds_f4)(uintptr_t)(4u * j);          // bvh_lds_l0: the records sit at 4 x the links' address
+            const f4v gv = *(lds_f4)(uintptr_t)j;
+            lk = *(lds_u32)(uintptr_t)(j >> 2);                   // bvh_lds_l0: the records sit at 4 x the links' address
             g = make_float4(gv.x, gv.y, gv.z, gv.w);
         } else {
             lk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(L) + j);
@@ -431,10 +432,10 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
                 wa += 256u;
             }
         }
-        return (leaf || pass) ? j + 4u : lk;     // staged links already carry the LDS base
+        return (leaf || pass) ? j + (NLDS ? 16u : 4u) : lk;     // staged links are record addresses already
     };
-    const uint32_t jn = 4u * n + l0;
-    uint32_t j = 4u * i + l0;
+    const uint32_t jn = NLDS ? 4u * (4u * n + l0) : 4u * n;
+    uint32_t j = NLDS ? 4u * (4u * i + l0) : 4u * i;
     // Loop control in the scalar unit, one exit test per trip: the wave leaves when no lane walks any more, or -- once
     // some lane has finished -- when fewer than `tail` still do (`tail` >= 1 covers the first case whenever the loop was
     // entered; tail == 0, "never suspend", leaves through the loop condition).
@@ -457,7 +458,7 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
         if (walking != walking0 && (uint32_t)__builtin_popcountll(walking) < tail) break;
     }
     drain();
-    i = (j - l0) >> 2;
+    i = NLDS ? ((j >> 2) - l0) >> 2 : j >> 2;
 }
 
 // ---- kernel ---------------------------------------------------------------------------------------------
@@ -493,8 +494,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
             float4 r = A.bvh_rec[i];
             if (SGN) r.w *= 4.70197740328915e-38f;      // 2^-124: the clamped form of the node test (trace_bvh)
             sR[i] = r;
-            const uint32_t lk = A.bvh_link[i];      // inner links become LDS addresses of the target's link
-            sL[i] = (int)lk < 0 ? lk : lk + (uint32_t)(uintptr_t)sL;
+            const uint32_t lk = A.bvh_link[i];      // inner links become LDS addresses ...
+            sL[i] = (int)lk < 0 ? lk : 4u * (lk + (uint32_t)(uintptr_t)sL);      // ... of the target's RECORD (trace_bvh)
         }
     const float4* R = NLDS ? sR : A.bvh_rec;
     const uint32_t* L = NLDS ? sL : A.bvh_link;
