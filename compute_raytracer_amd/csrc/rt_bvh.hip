@@ -292,7 +292,7 @@ __device__ __forceinline__ void reversed_shadow_walk(bool shadow, v3 L, float li
 // completed and fewer than TAIL lanes are still walking, the call returns; the stragglers resume
 // in the next call, next to the fresh rays of the lanes that completed -- the long tail of a
 // wave's slowest rays no longer holds 64 lanes for a handful.
-template <bool SGN, bool NLDS, int CAP>
+template <bool SGN, bool NLDS, int CAP, bool ROOMY>
 __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
                                           const float4* __restrict__ geo, uint32_t* slot, unsigned long long* best,
                                           uint32_t& i, v3 o, v3 d, v3 wo, v3 wd, float madd, float& nearest, int& idx
@@ -393,9 +393,10 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const f4v* lds_f4;
     const uint32_t l0 = NLDS ? (uint32_t)(uintptr_t)L : 0u;                       // LDS address of L[0]
-    auto step = [&](uint32_t j) -> uint32_t {
-        uint32_t lk;
-        float4 g;
+    // One step in three parts, so that a trip can issue the NEXT node's loads before it appends the current leaf: the
+    // append is an exec-masked block of its own, and a wave issues in order -- with the loads behind it, every step
+    // waited for six scalar and vector instructions that the next test does not depend on (round 3).
+    auto fetch = [&](uint32_t j, float4& g, uint32_t& lk) {
         if (NLDS) {
             const f4v gv = *(lds_f4)(uintptr_t)j;
             lk = *(lds_u32)(uintptr_t)(j >> 2);                   // bvh_lds_l0: the records sit at 4 x the links' address
@@ -404,35 +405,29 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
             lk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(L) + j);
             g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R) + 4u * (size_t)j);
         }
-        bool pass;
+    };
+    auto passes = [&](const float4& g) -> bool {
         if (CLAMPED) {
             float nb;      // max(-b, 0) * 2^-62
             const float part = fma_vvv(hs.y, g.y, fma_vvv(hs.x, g.x, ps));
             asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nb) : "v"(hs.z), "v"(g.z), "v"(part));
             const float cp = fma_vvv(ms.z, g.z, fma_vvv(ms.y, g.y, fma_vvv(ms.x, g.x, g.w)));
-            pass = __builtin_fmaf(nb, nb, -qs) > cp;
+            return __builtin_fmaf(nb, nb, -qs) > cp;
         } else {
             const float b = fnma_vvv(h.z, g.z, fnma_vvv(h.y, g.y, fnma_vvv(h.x, g.x, p)));
             const float cp = fma_vvv(m.z, g.z, fma_vvv(m.y, g.y, fma_vvv(m.x, g.x, g.w)));
             const float bm = SGN ? min0(b) : b;
-            pass = __builtin_fmaf(bm, bm, -q) > cp;
+            return __builtin_fmaf(bm, bm, -q) > cp;
         }
-        const bool leaf = (int)lk < 0;
-#ifdef RT_BVH_COUNT
-        if (RT_BVH_COUNT == 6) g_steps += leaf ? 1u : 0u;                              // leaf tests (lane)
-        if (RT_BVH_COUNT == 7) g_steps += (!leaf && pass) ? 1u : 0u;                   // inner nodes passed (lane)
-        if (RT_BVH_COUNT == 8) g_steps += (!leaf && lk != j) ? 1u : 0u;                // inner nodes tested (lane; the sentinel links to itself)
-#endif
-        if (leaf && pass) {
-            if (NLDS) {   // the store and the advance in place: the compiler forms the new address in a second register and moves it back
-                *(lds_u32_w)(uintptr_t)wa = lk;
-                asm("v_add_u32_e32 %0, 0x100, %0" : "+v"(wa));
-            } else {
-                *(lds_u32_w)(uintptr_t)wa = lk;
-                wa += 256u;
-            }
+    };
+    auto append = [&](uint32_t lk) {
+        if (NLDS) {   // the store and the advance in place: the compiler forms the new address in a second register and moves it back
+            *(lds_u32_w)(uintptr_t)wa = lk;
+            asm("v_add_u32_e32 %0, 0x100, %0" : "+v"(wa));
+        } else {
+            *(lds_u32_w)(uintptr_t)wa = lk;
+            wa += 256u;
         }
-        return (leaf || pass) ? j + (NLDS ? 16u : 4u) : lk;     // staged links are record addresses already
     };
     const uint32_t jn = NLDS ? 4u * (4u * n + l0) : 4u * n;
     uint32_t j = NLDS ? 4u * (4u * i + l0) : 4u * i;
@@ -441,19 +436,32 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
     // entered; tail == 0, "never suspend", leaves through the loop condition).
     const uint64_t walking0 = __ballot(j != jn);
     uint64_t walking = walking0;
+    float4 g;
+    uint32_t lk;
+    fetch(j, g, lk);
     while (walking != 0ull) {
 #ifdef RT_BVH_COUNT   // development statistics: 1 = wave iterations, 2 = lane tests (reported as "rays")
         if (RT_BVH_COUNT == 1) g_steps += (threadIdx.x & 63u) == 0u ? 2u : 0u;
-        if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
 #endif
-        j = step(j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool pass = passes(g);
+            const bool leaf = (int)lk < 0;
 #ifdef RT_BVH_COUNT
-        if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
+            if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
+            if (RT_BVH_COUNT == 6) g_steps += leaf ? 1u : 0u;                              // leaf tests (lane)
+            if (RT_BVH_COUNT == 7) g_steps += (!leaf && pass) ? 1u : 0u;                   // inner nodes passed (lane)
+            if (RT_BVH_COUNT == 8) g_steps += (!leaf && lk != j) ? 1u : 0u;                // inner nodes tested (lane; the sentinel links to itself)
 #endif
-        j = step(j);
-        j = step(j);
-        j = step(j);
-        if (__builtin_expect(__ballot(wa >= wa0 + 256u * (uint32_t)(CAP - 3)) != 0ull, 0)) drain();      // room for the four entries of the next trip
+            const uint32_t here = lk;
+            j = (leaf || pass) ? j + (NLDS ? 16u : 4u) : lk;     // staged links are record addresses already
+            fetch(j, g, lk);
+            if (leaf && pass) append(here);
+        }
+        if (__builtin_expect(__ballot(wa >= wa0 + 256u * (uint32_t)(CAP - 3)) != 0ull, 0)) {   // room for the four entries of the next trip
+            drain();
+            if (!ROOMY) fetch(j, g, lk);      // again, rather than five registers kept alive across the evaluation (80-VGPR forms: 10 spilled otherwise)
+        }
         walking = __ballot(j != jn);
         if (walking != walking0 && (uint32_t)__builtin_popcountll(walking) < tail) break;
     }
@@ -611,10 +619,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
         else if (shadow) wo = sc.lightPos;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
-        trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx, nrays);
+        trace_bvh<SGN, NLDS, CAP, WAVES == 16>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx, nrays);
         if (walking && node == n) {
 #else
-        trace_bvh<SGN, NLDS, CAP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx);
+        trace_bvh<SGN, NLDS, CAP, WAVES == 16>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx);
         if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
 #endif
