@@ -357,11 +357,17 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
             const uint32_t e = i < total ? pool[i] : (lane << 24);
             const int owner = (int)(e >> 24);
             const int si = (int)(e & 0x00FFFFFFu);
+            // The candidate's exact record is requested BEFORE the six shuffles, not behind them (the compiler sinks an
+            // ordinary load into the branch that uses it); lanes without an item ask for sphere 0.  The wait is ours too.
+            typedef float f4r __attribute__((ext_vector_type(4)));
+            f4r gr;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(gr) : "v"((uint32_t)si << 4), "s"(geo) : "memory");
             const v3 oo = V(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
             const v3 od = V(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
             if (i < total) {
-                const float4 g = geo[si];
-                const float a2 = dot(od, od);                     // HK:308
+                float a2 = dot(od, od);                           // HK:308
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(gr), "+v"(a2) : : "memory");      // the record: needed from here on
+                const float4 g = make_float4(gr.x, gr.y, gr.z, gr.w);
                 const v3 oc = sub(oo, V(g.x, g.y, g.z));
                 const float b = 2.0f * dot(od, oc);               // HK:309
                 const float c = dot(oc, oc) - g.w;                // HK:310
