@@ -153,7 +153,11 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
         if (count == 0u) {                                          // RK:275
             if (COUNT) traces += 2.0f;                              // HK:242
             uint32_t i1 = left, i2 = left + 1u;
-            const NodeR c1 = load_node(T, left), c2 = load_node(T, left + 1u);
+            NodeR c1 = load_node(T, left), c2 = load_node(T, left + 1u);
+            // `left` and `count` of the children come WITH their boxes: left to itself the compiler loads three
+            // components of each corner, decides, and then asks memory again for the fourth of both children -- a
+            // second dependent round trip in every step of a traversal that is nothing but such round trips.
+            asm volatile("" : "+v"(c1.left), "+v"(c1.count), "+v"(c2.left), "+v"(c2.count));
             float d1 = hit_aabb(oo, inv, c1);                       // RK:279
             float d2 = hit_aabb(oo, inv, c2);                       // RK:280
             const bool swap = d1 > d2;                              // RK:283-290
