@@ -115,13 +115,13 @@
 #define RT_BVH_GRAB 256u   /* pixel slots per cursor atomic: a multiple of 64 (whole tiles) */
 #endif
 #ifndef RT_BVH_TAIL_SMALL
-#define RT_BVH_TAIL_SMALL 20   /* 8-wave workgroups (scenes up to ~1300 spheres), frames in flight: 16 / 20 / 24 = 1.864 / 1.855 / 1.861 ms (tools/tail_ab.py) */
+#define RT_BVH_TAIL_SMALL 16   /* 8-wave workgroups (scenes up to ~1300 spheres), frames in flight: 12 / 14 / 16 / 18 / 20 / 24 = 1.574 / 1.565 / 1.563 / 1.565 / 1.572 / 1.598 ms (profiles/r03/tail_sweep.log; round 2, slower steps: 20) */
 #endif
 #ifndef RT_BVH_TAIL_SERIAL
 #define RT_BVH_TAIL_SERIAL 12  /* ... when one frame has the chip to itself */
 #endif
 #ifndef RT_BVH_TAIL_LARGE
-#define RT_BVH_TAIL_LARGE 32   /* 16-wave workgroups and the global-memory form */
+#define RT_BVH_TAIL_LARGE 28   /* 16-wave workgroups and the global-memory form (C5: 20 / 24 / 28 / 32 / 40 = 18.16 / 18.02 / 17.98 / 18.05 / 18.61 ms) */
 #endif
 
 namespace rtk {
@@ -739,8 +739,8 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     a.bvh_tail = (uint32_t)TAIL;
     if (TAIL == RT_BVH_TAIL_SMALL && a.grid_share <= 1u) a.bvh_tail = RT_BVH_TAIL_SERIAL;
     // small shares (a rank of eight of a 4K frame: 1 M pixels) end sooner after they begin: 12 / 16 / 20 / 24 lanes =
-    // 0.298 / 0.300 / 0.302 / 0.307 ms per frame in flight (profiles/r02/knobs_w8.log)
-    else if (TAIL == RT_BVH_TAIL_SMALL && a.n_local_tiles * 8u * a.W < (1u << 22)) a.bvh_tail = 16u;
+    // 0.298 / 0.300 / 0.302 / 0.307 ms per frame in flight (profiles/r02/knobs_w8.log); round 3: 8 / 12 / 16 / 20 = 0.239 / 0.240 / 0.244 / 0.251
+    else if (TAIL == RT_BVH_TAIL_SMALL && a.n_local_tiles * 8u * a.W < (1u << 22)) a.bvh_tail = 12u;
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_TAIL")) a.bvh_tail = (uint32_t)atoi(e);
 #endif
