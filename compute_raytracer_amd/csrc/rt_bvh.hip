@@ -524,6 +524,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
     __syncthreads();
 
     const Scene sc = unpack_scene(A);
+    // FLAT: every face of the sky is the same single texel c, and a sample is c + (wu * 0 + wv * 0): c unless a weight is
+    // NaN (rt_device.h: cube_sample<1> -- major axis, two IEEE divisions, a texel fetch per sample).  The directions this
+    // kernel samples are all outputs of normalize(): their components are finite, not all zero, or NaN -- never infinite
+    // (x / |v| with an infinite |v| is 0 or NaN; with |v| underflowed to 0 every component is inf or NaN, at least
+    // two of them) -- and for such r the weights are NaN exactly when a component is: c + ((r.x * 0 + r.y * 0) + r.z * 0)
+    // has the general path's value, with the texel read once per wave instead of once per trip.
+    v3 sky_c = V(0.0f, 0.0f, 0.0f);
+    if (FLAT) {
+        const v3 c = texel(A.face[0], 1, 1, 0, 0, lut);
+        sky_c = V(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.x))),
+                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.y))),
+                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.z))));
+    }
+    auto flat_sky = [&](v3 r) -> v3 {
+        const float z = (r.x * 0.0f + r.y * 0.0f) + r.z * 0.0f;
+        return V(sky_c.x + z, sky_c.y + z, sky_c.z + z);
+    };
     const float light_l1 = (__builtin_fabsf(sc.lightPos.x) + __builtin_fabsf(sc.lightPos.y)) + __builtin_fabsf(sc.lightPos.z);
     const uint32_t tiles_x = (A.W + 7u) / 8u;
     const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
@@ -600,7 +617,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
                 if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
                     opix = (ty * 8u + row) * A.W + x;
                     ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
-                    if (FLAT && sc.bounces == 0u) fog = scale(sc.minIntensity, cube_sample<1>(A, rd, lut));   // no ray will be cast
+                    if (FLAT && sc.bounces == 0u) fog = scale(sc.minIntensity, flat_sky(rd));   // no ray will be cast
                     color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
                     affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
                     shadow = false;
@@ -639,7 +656,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
                 // the pixel = the sky along the PRIMARY direction, which is rd at bounce 0).
                 // A textured sky (!FLAT) is not sampled here at all: the lane leaves a record, sky_resolve does it.
                 v3 sky = V(0, 0, 0);
-                if (FLAT && (bounce == 0u || idx < 0)) sky = scale(sc.minIntensity, cube_sample<1>(A, rd, lut));
+                if (FLAT && (bounce == 0u || idx < 0)) sky = scale(sc.minIntensity, flat_sky(rd));
                 if (FLAT && bounce == 0u) fog = sky;
                 if (idx < 0) {                                           // RK:122-126
                     if (FLAT) color = divs(add(scale(sum, color), scale(affect, sky)), next);
