@@ -230,8 +230,11 @@ __device__ __forceinline__ float light_term(const Scene& sc, v3 dest, v3 normal,
                                             bool shit, float st) {
     if (shit) {
         const v3 hp = add(sc.lightPos, scale(st, sdir));         // RK:156
-        const float diff = length(sub(hp, dest));                // RK:157
-        if (diff < 0.005f) {                                     // RK:158-159
+        // RK:157-159: diff = length(hp - dest), `if (diff < 0.005)`.  The correctly rounded square root is monotone, so
+        // sqrt(x) < 0.005f exactly when x < 0x1.a36e2cp-16, the smallest float whose root rounds to 0.005f or more (NaN: false
+        // either way) -- the comparison without the sixteen instructions of an IEEE square root.
+        const v3 dv = sub(hp, dest);
+        if (dot(dv, dv) < 0x1.a36e2cp-16f) {
             const float power = clampf(dot(normal, V(-sdir.x, -sdir.y, -sdir.z)), sc.minIntensity, 1.0f);  // RK:160
             const float cap = sc.lightIntensity / (sc.lightIntensity + distance);                         // RK:161
             return power * cap;                                  // RK:162
