@@ -124,7 +124,13 @@ double rt_scene_min_radius(const float* records, uint32_t n) {
 void rt_plan(double scene_bound, double min_radius, const float* p, bool& filter_ok, uint32_t& signed_filter) {
     const double cam = std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
     const double lgt = std::sqrt((double)p[16] * p[16] + (double)p[17] * p[17] + (double)p[18] * p[18]);
-    const double reach = rt_reach(scene_bound, cam, lgt);
+    // the camera's basis vectors (forwards, right, up: p[4..6], p[8..10], p[12..14]) bound the primary directions the same
+    // way: below 2^20 the squared length of fw + hc rt + vc up cannot overflow, so normalize() never returns the zero
+    // vector (rt_bvh.hip: flat_sky relies on it); a NaN or absurd basis sends the frame to the literal kernel
+    double basis = 0.0;
+    for (int k = 4; k < 15; ++k)
+        if (k % 4 != 3) { const double a = std::fabs((double)p[k]); basis = (a != a || basis != basis) ? NAN : std::max(basis, a); }
+    const double reach = rt_reach(scene_bound, cam, basis != basis ? (double)NAN : std::max(lgt, basis));   // std::max keeps a NaN first operand
     filter_ok = reach == reach && reach < 1048576.0;
     signed_filter = (filter_ok && 2.0 * reach * 7.3e-7 < 5.0e-4 && min_radius >= 9.313225746154785e-10) ? 1u : 0u;   // 2^-30
 }

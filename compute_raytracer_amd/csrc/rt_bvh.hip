@@ -526,10 +526,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
     const Scene sc = unpack_scene(A);
     // FLAT: every face of the sky is the same single texel c, and a sample is c + (wu * 0 + wv * 0): c unless a weight is
     // NaN (rt_device.h: cube_sample<1> -- major axis, two IEEE divisions, a texel fetch per sample).  The directions this
-    // kernel samples are all outputs of normalize(): their components are finite, not all zero, or NaN -- never infinite
-    // (x / |v| with an infinite |v| is 0 or NaN; with |v| underflowed to 0 every component is inf or NaN, at least
-    // two of them) -- and for such r the weights are NaN exactly when a component is: c + ((r.x * 0 + r.y * 0) + r.z * 0)
-    // has the general path's value, with the texel read once per wave instead of once per trip.
+    // kernel samples are all outputs of normalize() of vectors whose squared length cannot overflow (sums of three unit
+    // vectors; fast mode keeps coordinates below 2^20): their components are finite and not all zero, or NaN, or -- |v|
+    // underflowed to 0 -- inf / NaN with at least two of them not finite.  For such r the weights are NaN exactly when
+    // (r.x * 0 + r.y * 0) + r.z * 0 is: c plus that has the general path's value (tests/test_shortcuts_cpu.py), with the
+    // texel read once per wave instead of once per trip.
     v3 sky_c = V(0.0f, 0.0f, 0.0f);
     if (FLAT) {
         const v3 c = texel(A.face[0], 1, 1, 0, 0, lut);
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
                     ro = pos;
                     rd = normalize(reflect(rd, normal));                     // RK:130
                     sdir = normalize(sub(ro, sc.lightPos));                  // RK:147
-                    distance = length(sdir);                                 // RK:148
+                    distance = length_of_unit(sdir);                         // RK:148
                     shadow = true;                                           // RK:153 next
                     node = 0u; t = 9999.0f; idx = -1;                        // shadow ray
                 }

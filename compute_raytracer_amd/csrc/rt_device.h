@@ -20,6 +20,20 @@ __device__ __forceinline__ v3 divs(v3 a, float s) { return V(a.x / s, a.y / s, a
 __device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float length(v3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ v3 normalize(v3 a) { return divs(a, length(a)); }
+// length() of a vector that is itself the output of normalize() (RK:148 takes the length of the normalised shadow
+// direction): the squared length is 1 + k ulps with a handful of k, and the correctly rounded root of such a number is
+// known without extracting it -- sqrt(1 + k 2^-23) = 1 + k 2^-24 - ..., a float or just under the midpoint of two, so its
+// bit pattern is 0x3F800000 + (k >> 1) (arithmetic shift; the same formula below 1, where the ulp halves).  Checked
+// against sqrtf for every |k| <= 4096 (tests/test_shortcuts_cpu.py); anything further from 1 (a NaN direction, say)
+// takes the square root proper.
+__device__ __forceinline__ float length_of_unit(v3 a) {
+    const float x = dot(a, a);
+    const int k = __float_as_int(x) - 0x3F800000;
+    const float quick = __int_as_float(0x3F800000 + (k >> 1));
+    const bool near_one = (uint32_t)(k + 4096) <= 8192u;
+    if (__builtin_expect(__ballot(!near_one) == 0ull, 1)) return quick;
+    return near_one ? quick : sqrtf(x);
+}
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 // WGSL reflect(e1, e2) = e1 - 2 * dot(e2, e1) * e2
 __device__ __forceinline__ v3 reflect(v3 e1, v3 e2) { return sub(e1, scale(2.0f * dot(e2, e1), e2)); }

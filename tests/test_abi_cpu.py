@@ -120,6 +120,12 @@ def test_filter_plan_nan_and_inf_are_sticky_wherever_the_record_sits():
     assert _plan(base, q) == (0, 0)                 # NaN camera
     q = p.copy(); q[17] = np.inf
     assert _plan(base, q) == (0, 0)                 # light at infinity
+    for k in (4, 9, 14):                            # the camera's basis: forwards.x, right.y, up.z
+        for bad in (np.nan, np.inf, 3.0e30, -2.0e6):
+            q = p.copy(); q[k] = bad
+            assert _plan(base, q) == (0, 0), (k, bad)   # a NaN or absurd basis: the literal kernel (normalize() may return 0)
+        q = p.copy(); q[k] = 500.0
+        assert _plan(base, q) == (1, 0)             # a long basis vector counts like a far camera
     assert _plan(base[:0], p) == (1, 1)             # empty scene
     s = base.copy(); s[3, 7] = 0.0
     assert _plan(s, p) == (1, 1)                    # a zero radius is fine (nothing to rescale) ...

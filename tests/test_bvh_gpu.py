@@ -304,3 +304,23 @@ def test_rescaled_node_test_and_its_guard(oracle, case):
     img, st = gpu_render(scene, 128, 80, 6, strict=False, variant=BVH)
     assert np.array_equal(img, ref), diff_stats(img, ref)
     assert st["rays"] == rays
+
+
+@pytest.mark.parametrize("basis", ["huge_forwards", "nan_up", "degenerate_zero"])
+def test_absurd_camera_bases_reach_the_literal_kernel(oracle, basis):
+    """The flat-sky form of bvh_pixels relies on normalize() never returning the zero vector, which takes a squared length
+    that overflows: a camera basis beyond 2^20 (or NaN) makes rt_plan hand the frame to the literal kernel; a zero basis
+    (every primary direction NaN) stays on the fast path.  All three: the oracle's frame."""
+    scene = rt.synthetic_scene(200, 77)
+    scene.camera.update()
+    if basis == "huge_forwards":
+        scene.camera.forwards = np.array([3.0e30, 1.0e29, -2.0e30], np.float32)
+    elif basis == "nan_up":
+        scene.camera.up = np.array([0.0, np.nan, 0.0], np.float32)
+    else:
+        scene.camera.forwards = np.zeros(3, np.float32); scene.camera.right = np.zeros(3, np.float32); scene.camera.up = np.zeros(3, np.float32)
+    W, H, B = 96, 64, 3
+    ref, _, rays = oracle_render(oracle, scene, W, H, B)
+    img, st = gpu_render(scene, W, H, B, strict=False, variant=4)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays
