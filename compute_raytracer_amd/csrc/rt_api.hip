@@ -484,6 +484,11 @@ int rt_write_nodes(rt_ctx* c, size_t byte_offset, const float* data, uint32_t n)
     if (byte_offset % 32u) return fail(RT_ERR_INVALID_ARG, "rt_write_nodes: byte_offset must be a multiple of the 32-byte node");
     const size_t bytes = (size_t)n * 32u, end = byte_offset + bytes;
     const size_t head_bytes = (size_t)kHeadNodes * 32u;
+    for (uint32_t i = 0; i < n; ++i) {              // u32(primitiveCount) as the kernel forms it (NaN and negatives: 0)
+        const float f = data[8u * (size_t)i + 7u];
+        const uint32_t cnt = !(f > 0.0f) ? 0u : (f >= 4294967040.0f ? 4294967295u : (uint32_t)f);
+        c->node_count_max = std::max(c->node_count_max, cnt);
+    }
     // the part of the write that falls into the head region updates the host's copy of it; frames carry that copy
     if (byte_offset < head_bytes && n) {
         const size_t hi = std::min(end, head_bytes);
@@ -828,6 +833,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.n_tri_lookup = (uint32_t)(c->d_tri_lookup.used / 4u);
         ts.n_blas_lookup = c->inst.lookup_on ? (uint32_t)c->inst.lookup.size() : (uint32_t)(c->d_blas_lookup[v].used / 4u);
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
+        ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
         ts.tile_order = nullptr; ts.tile_cost = nullptr;
 #ifdef RT355_DEV_EXPORTS
         if (order_set >= 0 && getenv("RT355_KEEP_TILE_COST")) RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));

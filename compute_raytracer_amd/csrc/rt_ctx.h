@@ -121,6 +121,7 @@ struct rt_ctx {
     } inst;
     uint64_t ver_gen[kVersions] = {0, 0, 0, 0};  // inst.gen each device version holds
     size_t nodes_used = 0;                       // bytes of the node buffer written so far (any version)
+    uint32_t node_count_max = 0;                 // largest u32(primitiveCount) of any node written so far (packed BLAS stack: <= 65535)
     uint32_t tex_w = 0, tex_h = 0;
     int scene_kind = 0;                    // 0 spheres, 1 triangles: the primitive type written last
     int mode = RT_MODE_FAST;

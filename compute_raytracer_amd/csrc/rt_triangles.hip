@@ -18,6 +18,8 @@
 // the normal's model transform are formed once for the final nearest hit (they depend only on
 // the winning triangle, its barycentrics and its BLAS, so deferring them is bit-exact).
 // Out-of-range indices follow the robustness rule the oracle fixes (clamp to the last element).
+#include <type_traits>
+
 #include "rt_device.h"
 #include "rt_tri_types.h"
 
@@ -45,7 +47,8 @@ __device__ __forceinline__ NodeR load_node(const RtTriScene& T, uint32_t i) {
 // The head of the node buffer (the TLAS: RR:184-192 writes it at offset 0) and the BLAS records are
 // staged in LDS by every workgroup: the TLAS walk and the per-instance set-up (matrix, root index)
 // are a chain of dependent loads that every ray of every pixel pays, sky pixels included.
-constexpr uint32_t kLdsNodes = 64u, kLdsBlas = 16u;
+// (48 nodes + 12 records: with the packed BLAS stack a workgroup then takes 10,176 bytes = 8 LDS granules, sixteen per CU)
+constexpr uint32_t kLdsNodes = 48u, kLdsBlas = 12u;
 struct TriLds { const float4* nodes; uint32_t n_nodes; const float* blas; uint32_t n_blas; };
 __device__ __forceinline__ NodeR load_node_head(const RtTriScene& T, const TriLds& L, uint32_t i) {
     if (i >= T.n_nodes) i = T.n_nodes - 1u;
@@ -125,9 +128,15 @@ __device__ __forceinline__ bool hit_triangle(const RtTriScene& T, uint32_t slot,
 // RK:246-332 traceBLAS (the normal transform RK:334-338 is deferred to finish_hit)
 // STK: the element type of the traversal stacks.  uint16_t when the node buffer has at most 65,536 entries:
 // an index is stored clamped to the last node, which is what load_node makes of it anyway.
-template <bool COUNT, typename STK>
+// PACKED: the loop needs of its current node only `count` and `left` -- the box was tested when the node was a child.
+// RK:304 pushes the far child's INDEX and RK:297 / 328 load the node again when it is popped: a dependent global load whose
+// result was in registers at push time.  The packed stack keeps (count << 16 | left) of the pushed child instead, in the
+// same slot under the same clamping: a pop is one LDS read.  Valid while every count, child index and lookup slot fits 16
+// bits, which the host checks when the buffers are written (rt_api.hip: packed_ok).
+template <bool COUNT, typename STK, bool PACKED>
 __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L, uint32_t bi, v3 o, v3 d, float& nearest,
-                                           TriHit& hit, STK* stack, uint32_t stride, float& traces) {
+                                           TriHit& hit, typename std::conditional<PACKED, uint32_t, STK>::type* stack,
+                                           uint32_t stride, float& traces) {
     float m[17];                                                    // mat4 column-major, m[4c + r]; m[16] root index
     if (bi < L.n_blas) {
 #pragma unroll
@@ -165,12 +174,18 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
             if (d1 > blasNearest) {                                 // RK:292
                 if (sp == 0u) break;
                 sp -= 1u;
-                node = load_node(T, stack[sclamp(sp) * stride]);    // RK:297-298
+                if (PACKED) { const uint32_t e = stack[sclamp(sp) * stride]; node.count = (float)(e >> 16); node.left = (float)(e & 0xFFFFu); }
+                else node = load_node(T, stack[sclamp(sp) * stride]);    // RK:297-298
             } else {
                 node = swap ? c2 : c1;                              // RK:302 tree[iChild1]
                 (void)i1;
-                if (d2 < blasNearest) {                             // RK:303
-                    stack[sclamp(sp) * stride] = (STK)(i2 < T.n_nodes ? i2 : T.n_nodes - 1u);   // RK:304 (no overflow guard upstream)
+                if (d2 < blasNearest) {                             // RK:303, RK:304 (no overflow guard upstream)
+                    if (PACKED) {
+                        const uint32_t fc = u32f(swap ? c1.count : c2.count), fl = u32f(swap ? c1.left : c2.left);
+                        stack[sclamp(sp) * stride] = ((fc < 0xFFFFu ? fc : 0xFFFFu) << 16) | (fl < 0xFFFFu ? fl : 0xFFFFu);
+                    } else {
+                        stack[sclamp(sp) * stride] = (STK)(i2 < T.n_nodes ? i2 : T.n_nodes - 1u);
+                    }
                     sp += 1u;
                 }
             }
@@ -187,16 +202,17 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
             }
             if (sp == 0u) break;                                    // RK:324
             sp -= 1u;
-            node = load_node(T, stack[sclamp(sp) * stride]);        // RK:328-329
+            if (PACKED) { const uint32_t e = stack[sclamp(sp) * stride]; node.count = (float)(e >> 16); node.left = (float)(e & 0xFFFFu); }
+            else node = load_node(T, stack[sclamp(sp) * stride]);        // RK:328-329
         }
     }
     nearest = blasNearest < nearest ? blasNearest : nearest;        // RK:227-229: nearestHit = newRenderState.t on a hit
 }
 
 // RK:168-244 traceTLAS.  tstack / bstack: this lane's two LDS stacks.
-template <bool COUNT, typename STK>
+template <bool COUNT, typename STK, bool PACKED>
 __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& L, v3 o, v3 d, STK* tstack,
-                                             STK* bstack, uint32_t stride, float& traces) {
+                                             typename std::conditional<PACKED, uint32_t, STK>::type* bstack, uint32_t stride, float& traces) {
     TriHit hit; hit.t = 0.0f; hit.u = hit.v = 0.0f; hit.tri = -1; hit.blas = -1;   // RK:170-171
     float nearest = 9999.0f;                                        // RK:172
     const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -232,7 +248,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
                 if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
                 uint32_t bi = u32f(T.blas_lookup[li]);              // RK:223
                 if (bi >= T.n_blas) bi = T.n_blas - 1u;
-                trace_blas<COUNT, STK>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
+                trace_blas<COUNT, STK, PACKED>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
             }
             if (sp == 0u) break;                                    // RK:233
             sp -= 1u;
@@ -287,11 +303,13 @@ __device__ inline v3 tex2d_sample(const RtTriScene& T, float u, float v) {
 
 // ---- kernel: RK main over the triangle scene ---------------------------------------------------------
 // FLAT: compiled for a one-colour 1x1 sky (A.sky_flat) -- no cube filtering code inside the traversal's register budget.
-template <int WAVES, typename STK, int OCC, bool FLAT>
+template <int WAVES, typename STK, int OCC, bool FLAT, bool PACKED>
 __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
-    __shared__ STK stacks[2 * kStack * 64 * WAVES];
-    STK* tstack = stacks + threadIdx.x;
-    STK* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
+    typedef typename std::conditional<PACKED, uint32_t, STK>::type BSTK;
+    __shared__ STK tstacks[kStack * 64 * WAVES];
+    __shared__ BSTK bstacks[kStack * 64 * WAVES];
+    STK* tstack = tstacks + threadIdx.x;
+    BSTK* bstack = bstacks + threadIdx.x;
     constexpr uint32_t stride = 64 * WAVES;
     __shared__ float4 s_nodes[2 * kLdsNodes];
     __shared__ float s_blas[20 * kLdsBlas];
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     v3 ro = sc.cameraPos, rd = primary_dir(A, sc, x, y);
     float affect = 1.0f, sum = 0.0f;
     for (uint32_t bounce = 0; bounce < sc.bounces; ++bounce) {                       // RK:113
-        const TriHit h = trace_tlas<false, STK>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
+        const TriHit h = trace_tlas<false, STK, PACKED>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
         ++nrays;
         const bool hit = h.tri >= 0;
         if (bounce == 0) dist = hit ? h.t : 0.0f;                                    // RK:116-118
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
         // RK:146-166
         const v3 sdir = normalize(sub(ro, sc.lightPos));
         const float distance = length(sdir);
-        const TriHit sh = trace_tlas<false, STK>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
+        const TriHit sh = trace_tlas<false, STK, PACKED>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
         ++nrays;
         const float intensity = light_term(sc, ro, normal, sdir, distance, sh.tri >= 0, sh.t);
         const Albedo s = hit_albedo(T, tri, hu, hv);
@@ -416,11 +434,13 @@ __global__ __launch_bounds__(1024) void order_tiles(uint32_t* __restrict__ cost,
 }
 
 // ---- kernel: the heatmap twin (HK:63-83) ------------------------------------------------------------
-template <int WAVES, typename STK>
+template <int WAVES, typename STK, bool PACKED>
 __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArgs A, const RtTriScene T) {
-    __shared__ STK stacks[2 * kStack * 64 * WAVES];
-    STK* tstack = stacks + threadIdx.x;
-    STK* bstack = stacks + kStack * 64 * WAVES + threadIdx.x;
+    typedef typename std::conditional<PACKED, uint32_t, STK>::type BSTK;
+    __shared__ STK tstacks[kStack * 64 * WAVES];
+    __shared__ BSTK bstacks[kStack * 64 * WAVES];
+    STK* tstack = tstacks + threadIdx.x;
+    BSTK* bstack = bstacks + threadIdx.x;
     constexpr uint32_t stride = 64 * WAVES;
     __shared__ float4 s_nodes[2 * kLdsNodes];
     __shared__ float s_blas[20 * kLdsBlas];
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(64 * WAVES) void heatmap_triangles(const RtFrameArg
     const Scene sc = unpack_scene(A);
     const v3 dir0 = primary_dir(A, sc, x, y);                                        // HK:66-76
     float traces = 0.0f;
-    (void)trace_tlas<true, STK>(T, L, sc.cameraPos, dir0, tstack, bstack, stride, traces);   // HK:96-99, one bounce
+    (void)trace_tlas<true, STK, PACKED>(T, L, sc.cameraPos, dir0, tstack, bstack, stride, traces);   // HK:96-99, one bounce
     const float g = clampf(traces / 300.0f, 0.0f, 1.0f);                             // HK:79
     const uint32_t q = unorm8(g * 1.0f);                                             // HK:81-82
     const uint32_t opix = (blockIdx.y * 8u + row) * A.W + x;
@@ -471,14 +491,14 @@ hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* loo
 // WAVES: one wave per workgroup -- a workgroup's LDS and wave slots come free as soon as its own tile is done
 // (1 / 2 / 4 / 8 waves: 0.545 / 0.571 / 0.603 / 0.624 ms for the 1344x846 frame one at a time, 0.769 / 0.765 /
 // 0.792 / 0.883 ms per 4K frame in flight; profiles/r02/tri_waves.log).
-template <typename STK, int OCC, int WAVES = 1>
+template <typename STK, int OCC, bool PACKED, int WAVES = 1>
 static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
     const dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
     const uint32_t n_tiles = grid.x * grid.y;       // trace_triangles decodes the tile itself; with a work list: room for the quarters
     const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) : n_tiles, 1, 1);   // order_tiles: at most that many tiles in quarters
-    if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK>), grid, dim3(64 * WAVES), 0, s, a, t);
-    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true>), line, dim3(64 * WAVES), 0, s, a, t);
-    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false>), line, dim3(64 * WAVES), 0, s, a, t);
+    if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK, PACKED>), grid, dim3(64 * WAVES), 0, s, a, t);
+    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED>), line, dim3(64 * WAVES), 0, s, a, t);
+    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED>), line, dim3(64 * WAVES), 0, s, a, t);
 }
 
 hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
@@ -490,7 +510,8 @@ hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_til
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
     g_rt_kernel_id = heatmap ? RT_KID_HEATMAP : RT_KID_TRIANGLES;
-    if (t.n_nodes <= 65536u) launch_tri<uint16_t, 4>(a, t, heatmap, s);
-    else                     launch_tri<uint32_t, 3>(a, t, heatmap, s);      // 44 KB of stacks: three workgroups per CU
+    if (t.n_nodes <= 65536u && t.packed_ok) launch_tri<uint16_t, 4, true>(a, t, heatmap, s);
+    else if (t.n_nodes <= 65536u)           launch_tri<uint16_t, 4, false>(a, t, heatmap, s);
+    else                                    launch_tri<uint32_t, 3, false>(a, t, heatmap, s);      // 44 KB of stacks: three workgroups per CU
     return hipGetLastError();
 }

@@ -222,3 +222,23 @@ def test_tile_order_does_not_change_the_picture(oracle):
             assert np.array_equal(host[frame].reshape(H, W, 4), want[frame].reshape(H, W, 4)), frame
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("heatmap", [False, True])
+def test_scenes_beyond_the_packed_stack_take_the_index_stack(oracle, heatmap):
+    """The BLAS traversal keeps (count, left) of a pushed child in a 32-bit stack entry while every count, node index and
+    lookup slot fits 16 bits (rt_api.hip: packed_ok); a lookup table of more than 65,536 entries -- here: the scene's own
+    plus unused padding -- takes the form that pushes indices.  Both render the reference's frame."""
+    scene, mat = triangle_scene(seed=5, n_models=2, rings=7, sectors=9)
+    scene.static["tri_lookup"] = np.concatenate([np.asarray(scene.static["tri_lookup"], np.float32), np.zeros(70000, np.float32)])
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    W, H, B = 200, 120, 3
+    b = tri_buffers(scene, mat)
+    if heatmap:
+        ref, _ = oracle.heatmap_tri(scene.pack_params(B), b, W, H)
+        img, _ = gpu_render_tri(scene, mat, W, H, B, skybox=sky, heatmap=True)
+    else:
+        ref, _, rays = oracle.render_tri(scene.pack_params(B), b, sky.faces, W, H)
+        img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky)
+        assert st["rays"] == rays
+    assert np.array_equal(img, ref), diff_stats(img, ref)
