@@ -49,7 +49,7 @@ __device__ __forceinline__ NodeR load_node(const RtTriScene& T, uint32_t i) {
 // are a chain of dependent loads that every ray of every pixel pays, sky pixels included.
 // (48 nodes + 12 records: with the packed BLAS stack a workgroup then takes 10,176 bytes = 8 LDS granules, sixteen per CU)
 constexpr uint32_t kLdsNodes = 48u, kLdsBlas = 12u;
-struct TriLds { const float4* nodes; uint32_t n_nodes; const float* blas; uint32_t n_blas; };
+struct TriLds { const float4* nodes; uint32_t n_nodes; const float* blas; uint32_t n_blas; uint32_t n_lookup; };
 __device__ __forceinline__ NodeR load_node_head(const RtTriScene& T, const TriLds& L, uint32_t i) {
     if (i >= T.n_nodes) i = T.n_nodes - 1u;
     if (i >= L.n_nodes) return load_node(T, i);
@@ -65,7 +65,11 @@ __device__ __forceinline__ TriLds stage_head(const RtTriScene& T, float4* s_node
     L.n_nodes = T.n_nodes < kLdsNodes ? T.n_nodes : kLdsNodes;
     L.n_blas = T.n_blas < kLdsBlas ? T.n_blas : kLdsBlas;
     for (uint32_t i = threadIdx.x; i < 2u * L.n_nodes; i += 64 * WAVES) s_nodes[i] = T.nodes[i];
-    for (uint32_t i = threadIdx.x; i < 20u * L.n_blas; i += 64 * WAVES) s_blas[i] = T.blas[i];
+    // (the last padding word of staged record k carries entry k of the BLAS lookup table, RK:223: one dependent global load
+    // less per instance and ray)
+    L.n_lookup = T.n_blas_lookup < L.n_blas ? T.n_blas_lookup : L.n_blas;
+    for (uint32_t i = threadIdx.x; i < 20u * L.n_blas; i += 64 * WAVES)
+        s_blas[i] = (i % 20u == 19u && i / 20u < L.n_lookup) ? T.blas_lookup[i / 20u] : T.blas[i];
     __syncthreads();
     L.nodes = s_nodes; L.blas = s_blas;
     return L;
@@ -246,7 +250,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
             for (uint32_t i = 0; i < count; ++i) {                  // RK:220
                 uint32_t li = i + left;
                 if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
-                uint32_t bi = u32f(T.blas_lookup[li]);              // RK:223
+                uint32_t bi = u32f(li < L.n_lookup ? L.blas[20u * li + 19u] : T.blas_lookup[li]);   // RK:223
                 if (bi >= T.n_blas) bi = T.n_blas - 1u;
                 trace_blas<COUNT, STK, PACKED>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
             }
