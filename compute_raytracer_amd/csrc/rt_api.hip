@@ -193,17 +193,18 @@ int rt_create(int device, rt_ctx** out) {
     for (int i = 0; i < RT355_MAX_IN_FLIGHT && err == hipSuccess; ++i) {
         if ((err = hipEventCreate(&c->ev_prep0[i])) != hipSuccess) break;
         if ((err = hipEventCreate(&c->ev_k0[i])) != hipSuccess) break;
-        err = hipEventCreate(&c->ev_k1[i]);
+        if ((err = hipEventCreate(&c->ev_k1[i])) != hipSuccess) break;
+        err = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
     }
     if (err != hipSuccess ||
         (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), kCtrlBytes * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
         (err = hipMemset(c->d_rays, 0, kCtrlBytes * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
-        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), kCounterBytes,
+        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), 16u * RT355_MAX_IN_FLIGHT,
                              hipHostMallocDefault)) != hipSuccess) {
         rt_destroy(c);
         return fail_hip(err, "rt_create: stream/event/counter setup");
     }
-    std::memset(c->h_rays, 0, kCounterBytes);
+    std::memset(c->h_rays, 0, 16u * RT355_MAX_IN_FLIGHT);
     *out = c;
     return RT_OK;
 }
@@ -211,7 +212,7 @@ int rt_create(int device, rt_ctx** out) {
 int rt_destroy(rt_ctx* c) {
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
-    for (uint32_t i = 0; i < c->in_flight; ++i) (void)hipEventSynchronize(c->ev_k1[i]);
+    for (uint32_t i = 0; i < c->in_flight; ++i) (void)hipEventSynchronize(c->ev_done[i]);
     for (int k = 0; k < kStreams; ++k)
         if (c->streams[k]) (void)hipStreamSynchronize(c->streams[k]);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
@@ -238,6 +239,7 @@ int rt_destroy(rt_ctx* c) {
         if (c->ev_prep0[i]) (void)hipEventDestroy(c->ev_prep0[i]);
         if (c->ev_k0[i]) (void)hipEventDestroy(c->ev_k0[i]);
         if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
     }
     if (c->ev_scene) (void)hipEventDestroy(c->ev_scene);
     for (int k = 0; k < kStreams; ++k)
@@ -745,7 +747,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     }
 
     // this frame's partial ray counters and its 32-byte control block: one of RT355_MAX_IN_FLIGHT
-    // sets, all zeroed by rt_create and again by rt_wait (no per-frame memset or read-back)
+    // sets, all zeroed by rt_create and again by every frame's epilogue kernel (no memset or read-back by the host)
     unsigned long long* counters = c->d_rays + (kCtrlBytes / 8u) * slot;
     unsigned long long* ctrl = counters + kCounterBytes / 8u;
     for (int i = 0; i < 6; ++i) { fa.face[i] = c->d_face[i]; fa.fw[i] = c->fw[i]; fa.fh[i] = c->fh[i]; }
@@ -848,6 +850,9 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
+    // the frame's counters summed into host-visible memory and zeroed for the slot's next frame (rt_assemble.hip)
+    RT_HIP(rt_launch_frame_epilogue(counters, c->h_rays + 2u * slot, (uint32_t)(kCtrlBytes / 8u), s));
+    RT_HIP(hipEventRecord(c->ev_done[slot], s));
 #ifdef RT355_DEV_EXPORTS
     if (order_set >= 0 && getenv("RT355_KEEP_TILE_COST")) {      // tools/tile_cost_probe.py reads the times of whole tiles in index order
         c->order_tiles[order_set] = 0;
@@ -919,18 +924,13 @@ int rt_wait(rt_ctx* c) {
         // frames that end in an RCCL exchange: a poll that notices a failed peer or a missed deadline (rt_comm.hip)
         int rc = rt_comm_wait_frames(c);
         if (rc != RT_OK) return rc;
-    } else {
-        for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipEventSynchronize(c->ev_k1[i]));
     }
+    // one synchronisation per frame, on the event behind its epilogue kernel: ray count and fault word are in host memory
+    // by then, the counter set is zero again (rt_assemble.hip: frame_epilogue)
+    for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipEventSynchronize(c->ev_done[i]));
     if (c->in_flight) {
-        // ray count of the latest frame; then the counter sets of this batch are zeroed for the next
-        RT_HIP(hipMemcpyAsync(c->h_rays, c->d_rays + (kCtrlBytes / 8u) * (c->in_flight - 1u), kCounterBytes,
-                              hipMemcpyDeviceToHost, c->stream));
-        RT_HIP(hipMemsetAsync(c->d_rays, 0, kCtrlBytes * c->in_flight, c->stream));
-        RT_HIP(hipStreamSynchronize(c->stream));
         c->stats.frames += c->in_flight;
-        c->stats.rays = 0;
-        for (uint32_t k = 0; k < RT_RAY_COUNTERS; ++k) c->stats.rays += c->h_rays[k * (RT_RAY_COUNTER_STRIDE / 8u)];
+        c->stats.rays = c->h_rays[2u * (c->in_flight - 1u)];       // of the latest frame
         c->stats.batch_frames = c->in_flight;
         // Frames in flight?  Only the library's own rotation counts: a host that enqueues several frames on ONE stream
         // of its own (rt_render_to) has them serialised by that stream, and must not be given a quarter of the chip.
@@ -956,7 +956,8 @@ int rt_wait(rt_ctx* c) {
         c->in_flight = 0;
         for (int k = 0; k < kStreams; ++k) c->buf_slot[k] = -1;      // every frame of the batch is complete
         // a kernel that could not run as planned says so in the word behind its first ray counter (rt_device.h: report_fault)
-        const unsigned long long fault = c->h_rays[1];
+        unsigned long long fault = 0ull;
+        for (uint32_t i = 0; i < c->stats.batch_frames; ++i) fault = std::max(fault, c->h_rays[2u * i + 1u]);
         if (fault != 0ull) {
             char buf[160];
             std::snprintf(buf, sizeof buf, "rt_wait: the ray-trace kernel reported fault %llu (1: dynamic LDS not at address 0); the frame is incomplete", fault);

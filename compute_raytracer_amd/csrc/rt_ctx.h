@@ -48,6 +48,7 @@ struct rt_ctx {
     hipStream_t streams[kStreams] = {nullptr};   // rt_render rotates: consecutive frames may overlap on the device
     hipEvent_t ev_prep0[RT355_MAX_IN_FLIGHT] = {nullptr}, ev_k0[RT355_MAX_IN_FLIGHT] = {nullptr},
                ev_k1[RT355_MAX_IN_FLIGHT] = {nullptr};
+    hipEvent_t ev_done[RT355_MAX_IN_FLIGHT] = {nullptr};          // behind the frame's epilogue kernel: what rt_wait waits for
     hipEvent_t ev_scene = nullptr;       // the scene arrays / hierarchy a frame reads are complete ...
     hipStream_t scene_stream = nullptr;  // ... recorded on this stream
     uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
@@ -98,7 +99,7 @@ struct rt_ctx {
     unsigned long long* d_rays = nullptr;
     float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
     size_t queue_cap = 0;                  // entries
-    unsigned long long* h_rays = nullptr;  // pinned copy of the latest frame's partial counters
+    unsigned long long* h_rays = nullptr;  // pinned, device-visible: per frame in flight {rays, fault word}, written by the frame's epilogue kernel
     // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
     struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };
     DevBuf d_tri, d_tri_lookup, d_tex;

@@ -98,6 +98,7 @@ struct RtInstanceArgs {
     float data[31 * 8 + 16 * 20 + 16];                    // [head | blas | lookup]
 };
 hipError_t rt_launch_apply_instances(const RtInstanceArgs& a, hipStream_t s);
+hipError_t rt_launch_frame_epilogue(unsigned long long* counters, unsigned long long* host, uint32_t words, hipStream_t s);
 
 hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
