@@ -652,6 +652,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
 #endif
             const float next = affect + sum;                             // RK:120
             if (!shadow) {
+                // The centre and colour of the sphere a reflection ray has hit are requested HERE, by hand, and awaited
+                // where they are used: a wave issues in order, and the miss branch of the other lanes (three IEEE divisions)
+                // stands in between -- cycles the two loads used to add to every trip instead of sharing.  Lanes without a
+                // hit ask for sphere 0 and ignore the answer.
+                typedef float f3r __attribute__((ext_vector_type(3)));
+                f3r hit_g, hit_c;
+                {
+                    const uint32_t off = (uint32_t)(idx < 0 ? 0 : idx) << 4;
+                    asm volatile("global_load_dwordx3 %0, %2, %3\n\tglobal_load_dwordx3 %1, %2, %4"
+                                 : "=&v"(hit_g), "=&v"(hit_c) : "v"(off), "s"(A.geo), "s"(A.col) : "memory");
+                }
                 if (bounce == 0u) dist = idx >= 0 ? t : 0.0f;            // RK:116-118
                 // One sky sample serves RK:124 (the ray missed) and RK:93-96 (the fog colour of
                 // the pixel = the sky along the PRIMARY direction, which is rd at bounce 0).
@@ -663,12 +674,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
                     if (FLAT) color = divs(add(scale(sum, color), scale(affect, sky)), next);
                     else missed = true;
                     finished = true;
-                } else {
-                    const float4 g = A.geo[idx];
-                    const float4 cl4 = A.col[idx];
-                    albedo = V(cl4.x, cl4.y, cl4.z);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hit_g), "+v"(hit_c) : : "memory");
+                if (idx >= 0) {
+                    albedo = V(hit_c.x, hit_c.y, hit_c.z);
                     const v3 pos = add(ro, scale(t, rd));                    // RK:129
-                    normal = normalize(sub(pos, V(g.x, g.y, g.z)));          // HK:320
+                    normal = normalize(sub(pos, V(hit_g.x, hit_g.y, hit_g.z)));   // HK:320
                     ro = pos;
                     rd = normalize(reflect(rd, normal));                     // RK:130
                     sdir = normalize(sub(ro, sc.lightPos));                  // RK:147
