@@ -10,6 +10,7 @@
 #include <mutex>
 #include <thread>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -154,6 +155,7 @@ const char* rt_kernel_name(int id) {
         case RT_KID_HIERARCHY_GLOBAL: return "bvh_pixels<global>";
         case RT_KID_TRIANGLES: return "trace_triangles";
         case RT_KID_HEATMAP: return "heatmap_triangles";
+        case RT_KID_TRIANGLES_FLOW: return "trace_flow";
         default: return "none";
     }
 }
@@ -182,6 +184,7 @@ int rt_create(int device, rt_ctx** out) {
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return fail(RT_ERR_HIP, "rt_create: out of host memory");
     c->device = device;
+    c->n_cus = (uint32_t)prop.multiProcessorCount;
     c->wave_slots = (uint32_t)prop.multiProcessorCount * 16u;      // 4 SIMDs x 4 waves of the triangle kernel (launch_tri: OCC)
     hipError_t err;
     err = hipSuccess;
@@ -229,7 +232,8 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
-    for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex, &c->d_corners}) (void)hipFree(b->p);
+    for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex, &c->d_corners, &c->d_flow}) (void)hipFree(b->p);
+    for (int k = 0; k < kStreams; ++k) (void)hipFree(c->d_flow_ovf[k].p);
     for (int k = 0; k < kStreams; ++k) { (void)hipFree(c->d_tile_cost[k].p); (void)hipFree(c->d_tile_order[k].p); }
     for (int v = 0; v < kVersions; ++v)
         for (rt_ctx::DevBuf* b : {&c->d_nodes[v], &c->d_blas[v], &c->d_blas_lookup[v]}) (void)hipFree(b->p);
@@ -491,6 +495,12 @@ int rt_write_nodes(rt_ctx* c, size_t byte_offset, const float* data, uint32_t n)
         const uint32_t cnt = !(f > 0.0f) ? 0u : (f >= 4294967040.0f ? 4294967295u : (uint32_t)f);
         c->node_count_max = std::max(c->node_count_max, cnt);
     }
+    if (n) {                                        // the mirror the relinked copy of the BLAS trees is built from (rt_flow_build.h)
+        if (c->h_nodes.size() < end / 4u) c->h_nodes.resize(end / 4u, 0.0f);
+        std::memcpy(reinterpret_cast<char*>(c->h_nodes.data()) + byte_offset, data, bytes);
+        if (!c->flow_dirty && end / 32u > c->flow.min_node) c->flow_dirty = true;      // the write reaches nodes the copy was built from
+        if (end / 32u > c->flow.n_nodes) c->flow_dirty = true;                          // the buffer grew: the clamp-to-last-node rule moves
+    }
     // the part of the write that falls into the head region updates the host's copy of it; frames carry that copy
     if (byte_offset < head_bytes && n) {
         const size_t hi = std::min(end, head_bytes);
@@ -629,7 +639,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     bool sky_flat = true;       // six 1x1 faces of one colour
     for (int i = 0; i < 6; ++i)
         if (c->fw[i] != 1u || c->fh[i] != 1u || c->face_texel0[i] != c->face_texel0[0]) sky_flat = false;
-    const bool resolve_pass = use_bvh && !sky_flat;      // rt_bvh.hip: sky_resolve
+    bool resolve_pass = use_bvh && !sky_flat;      // rt_bvh.hip: sky_resolve (hierarchy kernel; the persistent triangle kernel joins below)
     if (resolve_pass) { int rc = ensure_fin(c); if (rc != RT_OK) return rc; }
     // The hierarchy after rt_write_spheres.  A changed sphere count (or the first frame): host build, here and
     // now.  The same count: the topology on the device stays, its node bounds are refitted there (below);
@@ -662,6 +672,63 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             c->bvh_cap = nodes + 1u;
         }
         c->bvh_nodes = nodes;
+    }
+    // ---- what the triangle kernels read beside the reference's buffers: built here, BEFORE a slot of the event ring is
+    // taken (both may have to drain the frames in flight, which empties the ring) ----
+    if (tri && !c->corners_valid) {
+        // the compact corner array follows the triangles and the lookup table
+        { int rc = drain(c); if (rc != RT_OK) return rc; }
+        const uint32_t n_slots = (uint32_t)(c->d_tri_lookup.used / 4u);
+        { int rc = grow_buf(c, c->d_corners, (size_t)n_slots * 48u); if (rc != RT_OK) return rc; }
+        if (c->scene_stream && c->scene_stream != s) RT_HIP(hipStreamWaitEvent(s, c->ev_scene, 0));
+        RT_HIP(rt_launch_tri_corners(static_cast<float4*>(c->d_corners.p), static_cast<const float*>(c->d_tri.p),
+                                     static_cast<const float*>(c->d_tri_lookup.p), n_slots, (uint32_t)(c->d_tri.used / 160u), s));
+        RT_HIP(hipEventRecord(c->ev_scene, s));          // frames on other streams wait for it (the scene-update event)
+        c->scene_stream = s;
+        c->corners_valid = true;
+    }
+    // The persistent kernel (rt_flow.hip) takes scenes whose instance data travels with the frame (up to 16 instances) and
+    // whose indices fit 16 bits; it reads the BLAS trees from the relinked copy, rebuilt when a write has reached the nodes
+    // it was made from or a frame names a root it does not know.
+    bool use_flow = false;
+    RtFlowArgs fl;
+    std::memset(&fl, 0, sizeof fl);
+    if (tri && c->kernel != RT_KERNEL_HEATMAP && c->variant != 6) {
+        const uint32_t n_nodes = (uint32_t)(c->nodes_used / 32u);
+        const uint32_t n_inst = (uint32_t)(c->inst.blas.size() / 20u);
+        const bool fits = c->inst.blas_on && c->inst.lookup_on && n_inst >= 1u && n_inst <= kFlowInst && !c->inst.lookup.empty() &&
+                          c->inst.lookup.size() <= kFlowInst && n_nodes >= 1u && n_nodes <= 65536u && c->d_tri_lookup.used / 4u <= 65536u &&
+                          c->node_count_max <= 65535u && c->h_nodes.size() / 8u >= n_nodes;
+        if (fits) {
+            uint32_t roots[kFlowInst];
+            for (uint32_t i = 0; i < n_inst; ++i) roots[i] = rt_flow_u32f(c->inst.blas[20u * i + 16u]);
+            // (the per-frame head of the node buffer lives in inst.head until a frame carries it: the mirror has it already)
+            if (c->flow_dirty || c->flow.n_nodes != n_nodes || !rt_flow_covers(c->flow, roots, n_inst)) {
+                { int rc = drain(c); if (rc != RT_OK) return rc; }
+                rt_flow_build(c->h_nodes.data(), n_nodes, roots, n_inst, c->flow);
+                c->flow_dirty = false;
+                if (c->flow.ok && c->flow.n_pairs) {
+                    int rc = write_buf(c, c->d_flow, 0, c->flow.pairs.data(), (size_t)c->flow.n_pairs * 64u, "flow pairs");
+                    if (rc != RT_OK) return rc;
+                }
+            }
+            if (c->flow.ok) {
+                for (int k = 0; k < kStreams; ++k)
+                    if (!c->d_flow_ovf[k].p) {
+                        const size_t bytes = (size_t)c->n_cus * 16u * kFlowOvfWords * 4u;
+                        RT_HIP(hipMalloc(&c->d_flow_ovf[k].p, bytes));
+                        c->d_flow_ovf[k].cap = bytes;
+                    }
+                if (!sky_flat) { int rc = ensure_fin(c); if (rc != RT_OK) return rc; resolve_pass = true; }   // rt_flow.hip leaves records for sky_resolve too
+                use_flow = true;
+                fl.pairs = static_cast<const float4*>(c->d_flow.p);
+                fl.n_pairs = c->flow.n_pairs;
+                fl.thresh = 24u;
+                const uint32_t last = n_nodes - 1u;
+                for (uint32_t i = 0; i < n_inst; ++i)
+                    fl.root_meta[i] = rt_flow_meta(c->h_nodes.data(), n_nodes, roots[i] < last ? roots[i] : last, c->flow.pair_of);
+            }
+        }
     }
     if (c->in_flight == RT355_MAX_IN_FLIGHT) {   // event ring full: drain
         int rc = rt_wait(c);
@@ -792,7 +859,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     const uint32_t order_n = ((c->W + 7u) / 8u) * fa.n_local_tiles;
     // ... and only for a caller that waits after each frame (the reference's loop): with frames in flight the tiles of
     // the next frame fill the slots a long tile leaves idle anyway, and row-major order keeps neighbours in one L2
-    if (tri && c->kernel != RT_KERNEL_HEATMAP && order_n >= kOrderMinTiles && !hint) {
+    if (tri && !use_flow && c->kernel != RT_KERNEL_HEATMAP && order_n >= kOrderMinTiles && !hint) {
         for (int k = 0; k < kStreams; ++k) if (s == c->streams[k]) order_set = k;
         if (order_set >= 0 && c->d_tile_cost[order_set].cap < (size_t)order_n * 4u) {
             // only frames on this stream use the set: wait for them, not for the batch (no slot bookkeeping involved)
@@ -806,17 +873,6 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));   // tiles ADD their times
             c->order_tiles[order_set] = 0;
         }
-    }
-    if (tri && !c->corners_valid) {
-        // the compact corner array follows the triangles and the lookup table; both writes drained, nothing reads it now
-        const uint32_t n_slots = (uint32_t)(c->d_tri_lookup.used / 4u);
-        { int rc = grow_buf(c, c->d_corners, (size_t)n_slots * 48u); if (rc != RT_OK) return rc; }
-        for (uint32_t i = 0; i < c->in_flight; ++i) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[i], 0));
-        RT_HIP(rt_launch_tri_corners(static_cast<float4*>(c->d_corners.p), static_cast<const float*>(c->d_tri.p),
-                                     static_cast<const float*>(c->d_tri_lookup.p), n_slots, (uint32_t)(c->d_tri.used / 160u), s));
-        RT_HIP(hipEventRecord(c->ev_scene, s));          // frames on other streams wait for it (the scene-update event)
-        c->scene_stream = s;
-        c->corners_valid = true;
     }
     RT_HIP(hipEventRecord(c->ev_k0[slot], s));
     g_rt_kernel_id = RT_KID_NONE;
@@ -844,7 +900,28 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             ts.tile_cost = static_cast<uint32_t*>(c->d_tile_cost[order_set].p);
             if (c->order_tiles[order_set] == order_n) ts.tile_order = static_cast<const uint32_t*>(c->d_tile_order[order_set].p);
         }
-        RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
+        if (use_flow) {
+            // One 16-wave workgroup per CU when the frame has the chip to itself -- all the LDS the stacks leave goes to pair
+            // records --, one 4-wave workgroup per CU and frame when frames in flight share it.
+            uint32_t waves = fa.grid_share > 1u ? 4u : 16u, per_cu = fa.grid_share > 1u ? 4u : 1u, blocks = c->n_cus;
+#ifdef RT355_DEV_EXPORTS
+            if (const char* e = getenv("RT355_FLOW_WAVES")) { waves = (uint32_t)atoi(e); per_cu = 16u / waves; }
+            if (const char* e = getenv("RT355_FLOW_PERCU")) per_cu = (uint32_t)atoi(e);
+            if (const char* e = getenv("RT355_FLOW_BLOCKS")) blocks = (uint32_t)atoi(e);
+            if (const char* e = getenv("RT355_FLOW_THRESH")) fl.thresh = (uint32_t)atoi(e);
+            if (waves != 16u && waves != 8u && waves != 4u) waves = 16u;
+            if (per_cu < 1u) per_cu = 1u;
+            if (blocks * waves > c->n_cus * 16u) blocks = c->n_cus * 16u / waves;      // the overflow area is sized for that many waves
+#endif
+            const uint32_t pixels = fa.n_local_tiles * ((fa.W + 7u) / 8u) * 64u;
+            blocks = std::max(1u, std::min(blocks, (pixels + 64u * waves - 1u) / (64u * waves)));
+            // one overflow area per frame that may be running: the frame kStreams slots back must be through with this one
+            if (slot >= (uint32_t)kStreams) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[slot - (uint32_t)kStreams], 0));
+            fl.ovf = static_cast<uint32_t*>(c->d_flow_ovf[slot % (uint32_t)kStreams].p);
+            RT_HIP(rt_launch_flow(fa, ts, fl, waves, per_cu, blocks, s));
+        } else {
+            RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
+        }
     } else {
         if (use_bvh) RT_HIP(rt_launch_bvh(fa, s));
         else RT_HIP(rt_launch_trace(fa, cfg, s));
@@ -1060,6 +1137,21 @@ int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* 
     if (cap_nodes < nodes + 1u || !rec4 || !link) return fail(RT_ERR_CAPACITY, "rt_build_hierarchy: need n_nodes + 1 entries");
     std::memcpy(rec4, r.data(), r.size() * sizeof(float));
     std::memcpy(link, l.data(), l.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+int rt_build_flow(const float* nodes, uint32_t n_nodes, const uint32_t* roots, uint32_t n_roots, float* pairs, uint32_t cap_pairs,
+                  uint32_t* n_pairs, uint32_t* root_meta) {
+    if (!nodes || (n_roots && !roots) || !n_pairs) return fail(RT_ERR_INVALID_ARG, "rt_build_flow: NULL argument");
+    RtFlow f;
+    rt_flow_build(nodes, n_nodes, roots, n_roots, f);
+    *n_pairs = f.n_pairs;
+    if (!f.ok) return fail(RT_ERR_UNSUPPORTED, "rt_build_flow: node buffer beyond 65,536 entries or a count beyond 16 bits");
+    if (f.n_pairs && (cap_pairs < f.n_pairs || !pairs)) return fail(RT_ERR_CAPACITY, "rt_build_flow: need room for n_pairs records");
+    if (f.n_pairs) std::memcpy(pairs, f.pairs.data(), (size_t)f.n_pairs * 64u);
+    if (root_meta)
+        for (uint32_t r = 0; r < n_roots; ++r)
+            root_meta[r] = rt_flow_meta(nodes, n_nodes, roots[r] < n_nodes - 1u ? roots[r] : n_nodes - 1u, f.pair_of);
     return RT_OK;
 }
 

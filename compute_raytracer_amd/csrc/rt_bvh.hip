@@ -807,10 +807,7 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     if (!a.sky_flat && !a.fin) return hipErrorInvalidValue;
     g_rt_kernel_id = !NLDS ? RT_KID_HIERARCHY_GLOBAL : (WAVES == 8 ? RT_KID_HIERARCHY_8 : (WAVES == 12 ? RT_KID_HIERARCHY_12 : RT_KID_HIERARCHY_16));
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
-    if (!a.sky_flat) {
-        const uint32_t slots = a.n_local_tiles * 8u * a.W;
-        hipLaunchKernelGGL(sky_resolve, dim3(std::min((slots + 255u) / 256u, 256u * 8u)), dim3(256), 0, s, a);
-    }
+    if (!a.sky_flat) return rt_launch_sky_resolve(a, s);
     return hipGetLastError();
 }
 
@@ -843,6 +840,13 @@ extern "C" __attribute__((visibility("default"))) int rt_debug_wave_clock(unsign
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(rtk::g_wave_clock), n * sizeof(unsigned long long));
 }
 #endif
+
+hipError_t rt_launch_sky_resolve(const RtFrameArgs& a, hipStream_t s) {
+    const uint32_t slots = a.n_local_tiles * 8u * a.W;
+    if (slots == 0u) return hipSuccess;
+    hipLaunchKernelGGL(rtk::sky_resolve, dim3(std::min((slots + 255u) / 256u, 256u * 8u)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     return a.signed_filter ? rtk::launch_bvh<true>(a, s) : rtk::launch_bvh<false>(a, s);

@@ -1,0 +1,437 @@
+// rt_flow.hip -- the reference's live scene type (triangles behind a TLAS / BLAS hierarchy, RK:168-410) rendered by
+// PERSISTENT waves: every lane carries one pixel's path through a small state machine and takes the next pixel from the
+// frame's cursor when the path ends; the nested walks of the reference (traceTLAS around traceBLAS around the triangle
+// loop) are unrolled into single STEPS, and per trip a wave executes ONE kind of step -- the kind most of its lanes wait
+// for -- so that lanes at different bounces, instances and tree levels share every instruction they can.
+//
+// Why.  rt_triangles.hip keeps the WGSL's shape -- a pixel per lane for the pixel's whole life, a tile per wave -- and
+// measured (profiles/r03): a frame on its own takes as long as its longest tile (498 of 504 us), a wave waits on memory
+// 47 % of its cycles (a dependent global load per step, four waves per SIMD because two 20-entry stacks per lane fill the
+// LDS), and the paths of one tile diverge: 2.3e8 wave-instructions per frame of the reference's scene where its 44 M steps,
+// fully packed, need 7e7.  Here
+//   * pixels come from a cursor: no wave idles while another still has a tile's worth of paths (the frame ends with its
+//     longest PATH, 459 steps on the reference's scene, not its longest tile);
+//   * the BLAS trees are read from the library's relinked copy (rt_flow_build.h: 64-byte child PAIRS, most-visited first),
+//     whose head the workgroup stages in LDS -- 89-94 % of all inner-node steps of the reference's scene become LDS reads;
+//   * the per-lane stacks keep their first 8 (BLAS) / 2 (TLAS) slots in LDS and the rest in a per-wave overflow area in
+//     global memory (0.2 % of all pushes on the reference's scene go deeper than 8): 2.3 KB of LDS per wave instead of 7.7;
+//   * a step is a block of code of its own -- TLAS (inner node or instance set-up), BNODE (one child pair), TRI (one
+//     triangle), DONE (a ray is complete: shade, next ray / next pixel) -- chosen per trip by vote (tools/tri_sched_sim.c
+//     is the model: executing every block that has a lane costs 2.5 x the instructions of executing the fullest one).
+//
+// Bit-exactness is a scheduling argument: a lane's own sequence of operations on its own state is the sequential program
+// of RK:101-166 / RK:168-341 statement for statement (the helpers are rt_tri_device.h's, shared with rt_triangles.hip);
+// which lane holds which pixel, and when it advances, touches no value.  The relinked copy holds the reference's own box
+// corners; indices and counts are converted (u32(f32), clamp to the last element) when it is built instead of per step.
+//
+// Scenes this form takes (rt_api.hip: flow_ok): up to 16 instances and lookup entries (they travel with the frame), node
+// buffer and lookup table within 16 bits, a relinked copy that covers the frame's roots.  Everything else, and the
+// heatmap, stays with rt_triangles.hip.
+#include "rt_tri_device.h"
+#include "rt_flow_types.h"
+
+namespace rtk {
+
+enum : uint32_t { ST_IDLE = 0u, ST_TLAS = 1u, ST_BNODE = 2u, ST_TRI = 3u, ST_RDONE = 4u, ST_SDONE = 5u };
+
+#ifdef RT_FLOW_COUNT
+// counting build: [2k] runs of block k, [2k+1] lanes it advanced (k: 0 TLAS, 1 BNODE, 2 TRI, 3 DONE), [8] trips, [9] BNODE steps served from LDS
+__device__ unsigned long long g_flow_count[16];
+#endif
+
+__device__ __forceinline__ uint32_t pack_node(const NodeR& n) {
+    const uint32_t c = u32f(n.count), l = u32f(n.left);
+    return ((c < 0xFFFFu ? c : 0xFFFFu) << 16) | (l < 0xFFFFu ? l : 0xFFFFu);
+}
+
+template <int WAVES, bool FLAT>
+__global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A, const RtTriScene T, const RtFlowArgs F) {
+    extern __shared__ float4 lds[];
+    constexpr uint32_t stride = 64u * WAVES;
+    float4* const s_nodes = lds;                                                        // [2 * kLdsNodes]
+    float* const s_blas = reinterpret_cast<float*>(lds + 2u * kLdsNodes);               // [20 * kFlowInst]
+    uint32_t* const s_bstack = reinterpret_cast<uint32_t*>(s_blas + 20u * kFlowInst);   // [kFlowKB][stride]
+    uint16_t* const s_tstack = reinterpret_cast<uint16_t*>(s_bstack + kFlowKB * stride); // [kFlowKT][stride]
+    const float4* const s_pairs = reinterpret_cast<const float4*>(s_tstack + kFlowKT * stride);   // [lds_pairs][4]
+
+    // ---- staging: TLAS head, instance records (+ root meta, + lookup entry), the head of the pair array ----
+    TriLds L;
+    L.n_nodes = T.n_nodes < kLdsNodes ? T.n_nodes : kLdsNodes;
+    L.n_blas = T.n_blas < kFlowInst ? T.n_blas : kFlowInst;
+    L.n_lookup = T.n_blas_lookup < L.n_blas ? T.n_blas_lookup : L.n_blas;
+    for (uint32_t i = threadIdx.x; i < 2u * L.n_nodes; i += stride) s_nodes[i] = T.nodes[i];
+    for (uint32_t i = threadIdx.x; i < 20u * L.n_blas; i += stride) {
+        const uint32_t r = i / 20u, k = i % 20u;
+        float v = T.blas[i];
+        if (k == 17u) v = __uint_as_float(F.root_meta[r]);
+        if (k == 19u && r < L.n_lookup) v = T.blas_lookup[r];
+        s_blas[i] = v;
+    }
+    {
+        float4* const dst = const_cast<float4*>(s_pairs);
+        for (uint32_t i = threadIdx.x; i < 4u * F.lds_pairs; i += stride) dst[i] = F.pairs[i];
+    }
+    __syncthreads();
+    L.nodes = s_nodes; L.blas = s_blas;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* const bst = s_bstack + threadIdx.x;
+    uint16_t* const tst = s_tstack + threadIdx.x;
+    // overflow stacks of this wave: [kStack - kFlowKB][64] words, then [kStack - kFlowKT][64] half words
+    uint32_t* const ovf_b = F.ovf + (size_t)(blockIdx.x * WAVES + wave) * kFlowOvfWords + lane;
+    uint16_t* const ovf_t = reinterpret_cast<uint16_t*>(F.ovf + (size_t)(blockIdx.x * WAVES + wave) * kFlowOvfWords + (kStack - kFlowKB) * 64u) + lane;
+
+    const Scene sc = unpack_scene(A);
+    const uint32_t tiles_x = (A.W + 7u) / 8u;
+    const uint32_t total = A.n_local_tiles * tiles_x * 64u;      // pixel slots, tile-major
+    uint32_t cur = 0, end = 0;                                   // wave-uniform chunk of the cursor
+    uint32_t chunk_ty = 0, chunk_tx = 0, chunk_first = ~0u;
+    bool exhausted = false;
+    // the ray every path starts with enters the TLAS at node 0 (RK:175): its (count, left), once per wave
+    const uint32_t root_tnode = pack_node(load_node_head(T, L, 0u));
+
+    // ---- per-lane state ----
+    uint32_t st = ST_IDLE;
+    uint32_t opix = 0, xy = 0, bounce = 0, nrays = 0;
+    bool shadow = false;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), color = V(1, 1, 1);
+    v3 normal = V(0, 0, 1), sdir = V(0, 0, 1);
+    float dist = 0.0f, affect = 1.0f, sum = 0.0f;
+    int ptri = -1; float pu = 0.0f, pv = 0.0f;                   // the reflection ray's hit, kept for the albedo (RK:133-134)
+    // current ray: nearest hit so far (RK:172), and which triangle / instance it is on
+    float nearest = 9999.0f, hu = 0.0f, hv = 0.0f;
+    int htri = -1, hblas = -1;
+    // TLAS level (RK:168-244)
+    uint32_t tnode = 0, ti = 0, sp_t = 0;
+    // BLAS level (RK:246-332)
+    v3 oo = V(0, 0, 0), od = V(0, 0, 1), inv = V(0, 0, 0);
+    float bnear = 9999.0f;
+    uint32_t bnode = 0, tk = 0, sp_b = 0, cbi = 0;
+
+    if (sc.bounces == 0u) {
+        // RK:113: the loop body never runs -- colour (1,1,1), dist 0 (RK:102-103), composed with the fog colour
+        for (;;) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.qctrl[2], 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= total) break;
+            const uint32_t ty = (base >> 6) / tiles_x, tx = (base >> 6) - ty * tiles_x;
+            const uint32_t x = tx * 8u + (lane & 7u), row = lane >> 3;
+            const uint32_t y = (A.tile_first + ty * A.tile_step) * 8u + row;
+            if (x < A.W && y < A.H) {
+                const uint32_t o = (ty * 8u + row) * A.W + x;
+                if (FLAT) reinterpret_cast<uint32_t*>(A.out)[o] =
+                    compose_pixel_sky(scale(sc.minIntensity, cube_sample<1>(A, primary_dir(A, sc, x, y))), V(1.0f, 1.0f, 1.0f), 0.0f);
+                else A.fin[2u * o] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);      // sky_resolve composes it with the fog colour
+            }
+        }
+        return;
+    }
+
+#ifdef RT_FLOW_COUNT
+    uint32_t c_runs[4] = {0, 0, 0, 0}, c_lanes[4] = {0, 0, 0, 0}, c_trips = 0, c_lds = 0;
+#endif
+
+    // one hybrid-stack access: slot s of this lane, LDS below the split, the wave's overflow area above
+    auto bpush = [&](uint32_t s, uint32_t v) { if (s < kFlowKB) bst[s * stride] = v; else ovf_b[(s - kFlowKB) * 64u] = v; };
+    auto bread = [&](uint32_t s) -> uint32_t { return s < kFlowKB ? bst[s * stride] : ovf_b[(s - kFlowKB) * 64u]; };
+    auto tpush = [&](uint32_t s, uint32_t v) { if (s < kFlowKT) tst[s * stride] = (uint16_t)v; else ovf_t[(s - kFlowKT) * 64u] = (uint16_t)v; };
+    auto tread = [&](uint32_t s) -> uint32_t { return s < kFlowKT ? (uint32_t)tst[s * stride] : (uint32_t)ovf_t[(s - kFlowKT) * 64u]; };
+
+    // a new ray of this lane's path enters the TLAS (RK:170-178)
+    auto start_ray = [&]() {
+        tnode = root_tnode; ti = 0u; sp_t = 0u;
+        nearest = 9999.0f; htri = -1; hblas = -1;
+        st = ST_TLAS;
+    };
+    // RK:324-329 / RK:294-298: the BLAS walk needs its next node from the stack, or is over (RK:227-229, then the TLAS leaf's next instance)
+    auto blas_pop = [&]() {
+        if (sp_b == 0u) {
+            nearest = bnear < nearest ? bnear : nearest;
+            ti += 1u;
+            st = ST_TLAS;
+        } else {
+            sp_b -= 1u;
+            bnode = bread(sclamp(sp_b));
+            tk = 0u;
+            st = (bnode >> 16) == 0u ? ST_BNODE : ST_TRI;
+        }
+    };
+
+    for (;;) {
+        // ---- which block runs this trip ----
+        const uint32_t c_l = (uint32_t)__popcll(__ballot(st == ST_TLAS));
+        const uint32_t c_b = (uint32_t)__popcll(__ballot(st == ST_BNODE));
+        const uint32_t c_t = (uint32_t)__popcll(__ballot(st == ST_TRI));
+        const uint32_t c_d = (uint32_t)__popcll(__ballot(st >= ST_RDONE)) + (exhausted ? 0u : (uint32_t)__popcll(__ballot(st == ST_IDLE)));
+        const uint32_t walkers = c_l + c_b + c_t;
+        if (walkers == 0u && c_d == 0u) break;
+        uint32_t run;                                       // 0 TLAS, 1 BNODE, 2 TRI, 3 DONE
+        if (c_d >= F.thresh || walkers == 0u) run = 3u;
+        else if (c_b >= c_t && c_b >= c_l) run = 1u;
+        else if (c_t >= c_l) run = 2u;
+        else run = 0u;
+#ifdef RT_FLOW_COUNT
+        ++c_trips; ++c_runs[run];
+        c_lanes[run] += run == 0u ? c_l : (run == 1u ? c_b : (run == 2u ? c_t : c_d));
+#endif
+
+        if (run == 1u) {
+            // ---- BNODE: one step of RK:275-307 on the child pair of the current inner node ----
+            if (st == ST_BNODE) {
+                const uint32_t p = bnode & 0xFFFFu;
+                float4 q0, q1, q2, q3;
+                if (p < F.lds_pairs) {
+                    q0 = s_pairs[4u * p]; q1 = s_pairs[4u * p + 1u]; q2 = s_pairs[4u * p + 2u]; q3 = s_pairs[4u * p + 3u];
+#ifdef RT_FLOW_COUNT
+                    ++c_lds;
+#endif
+                } else {
+                    const float4* g = F.pairs + 4u * (size_t)p;
+                    q0 = g[0]; q1 = g[1]; q2 = g[2]; q3 = g[3];
+                }
+                NodeR c1, c2;
+                c1.lo = V(q0.x, q0.y, q0.z); c1.hi = V(q1.x, q1.y, q1.z);
+                c2.lo = V(q2.x, q2.y, q2.z); c2.hi = V(q3.x, q3.y, q3.z);
+                const uint32_t m1 = __float_as_uint(q0.w), m2 = __float_as_uint(q2.w);
+                float d1 = hit_aabb(oo, inv, c1);                       // RK:279
+                float d2 = hit_aabb(oo, inv, c2);                       // RK:280
+                const bool swap = d1 > d2;                              // RK:283-290
+                if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; }
+                if (d1 > bnear) {                                       // RK:292
+                    blas_pop();
+                } else {
+                    bnode = swap ? m2 : m1;                             // RK:302
+                    if (d2 < bnear) {                                   // RK:303-304 (no overflow guard upstream)
+                        bpush(sclamp(sp_b), swap ? m1 : m2);
+                        sp_b += 1u;
+                    }
+                    tk = 0u;
+                    st = (bnode >> 16) == 0u ? ST_BNODE : ST_TRI;
+                }
+            }
+        } else if (run == 2u) {
+            // ---- TRI: one trip of the leaf loop RK:311-322 ----
+            if (st == ST_TRI) {
+                const uint32_t count = bnode >> 16, left = bnode & 0xFFFFu;
+                uint32_t li = left + tk;
+                if (li >= T.n_tri_lookup) li = T.n_tri_lookup - 1u;     // RK:314: the lookup itself is folded into T.corners
+                float t, u, v;
+                if (hit_triangle(T, li, oo, od, bnear, t, u, v)) {      // RK:312-321
+                    bnear = t;
+                    hu = u; hv = v; htri = (int)li; hblas = (int)cbi;
+                }
+                tk += 1u;
+                if (tk >= count) blas_pop();                            // RK:324-329
+            }
+        } else if (run == 0u) {
+            // ---- TLAS: one step of RK:179-240 -- an inner node, or the next instance of a leaf ----
+            if (st == ST_TLAS) {
+                const uint32_t count = tnode >> 16, left = tnode & 0xFFFFu;
+                const v3 o = shadow ? sc.lightPos : ro, d = shadow ? sdir : rd;
+                bool pop = false;
+                if (count == 0u) {                                      // RK:183
+                    uint32_t i2 = left + 1u;
+                    const NodeR c1 = load_node_head(T, L, left), c2 = load_node_head(T, L, left + 1u);
+                    const v3 winv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    float d1 = hit_aabb(o, winv, c1);                   // RK:186
+                    float d2 = hit_aabb(o, winv, c2);                   // RK:187
+                    const bool swap = d1 > d2;                          // RK:190-196
+                    if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; i2 = left; }
+                    if (d1 > nearest) {                                 // RK:198
+                        pop = true;
+                    } else {
+                        tnode = pack_node(swap ? c2 : c1);              // RK:208
+                        ti = 0u;
+                        if (d2 < nearest) {                             // RK:209
+                            tpush(sclamp(sp_t), i2 < T.n_nodes ? i2 : T.n_nodes - 1u);
+                            sp_t += 1u;
+                            if (sp_t > kStack) sp_t = kStack - 1u;      // RK:212-214 guards with `>`
+                        }
+                    }
+                } else if (ti < count) {                                // RK:220: instance ti of this leaf (RK:246-269)
+                    uint32_t li = ti + left;
+                    if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
+                    uint32_t bi = u32f(li < L.n_lookup ? s_blas[20u * li + 19u] : T.blas_lookup[li]);   // RK:223
+                    if (bi >= T.n_blas) bi = T.n_blas - 1u;
+                    const float* m = s_blas + 20u * bi;                 // mat4 column-major, m[4c + r]; every instance is staged (flow_ok)
+                    oo = V(((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.0f,
+                           ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.0f,
+                           ((m[2] * o.x + m[6] * o.y) + m[10] * o.z) + m[14] * 1.0f);       // RK:254
+                    od = V(((m[0] * d.x + m[4] * d.y) + m[8] * d.z) + m[12] * 0.0f,
+                           ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.0f,
+                           ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.0f);       // RK:255
+                    inv = V(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);     // RK:396
+                    bnode = __float_as_uint(m[17]);                     // RK:265: the root's (count, left), relinked
+                    cbi = bi;
+                    sp_b = 0u;                                          // RK:267
+                    bnear = nearest;                                    // RK:269
+                    tk = 0u;
+                    st = (bnode >> 16) == 0u ? ST_BNODE : ST_TRI;
+                } else {
+                    pop = true;                                         // RK:233
+                }
+                if (pop) {
+                    if (sp_t == 0u) {
+                        st = shadow ? ST_SDONE : ST_RDONE;              // the ray is complete
+                    } else {
+                        sp_t -= 1u;
+                        tnode = pack_node(load_node_head(T, L, tread(sclamp(sp_t))));   // RK:237-238
+                        ti = 0u;
+                    }
+                }
+            }
+        } else {
+            // ---- DONE: complete rays are shaded (RK:114-141, RK:146-166), finished pixels stored, idle lanes refilled ----
+            bool finished = false, missed = false;
+            if (st == ST_RDONE) {
+                ++nrays;
+                const bool hit = htri >= 0;
+                if (bounce == 0u) dist = hit ? nearest : 0.0f;                           // RK:116-118
+                if (!hit) {
+                    missed = true; finished = true;                                      // RK:122-126, blended below
+                } else {
+                    TriHit h; h.t = nearest; h.u = hu; h.v = hv; h.tri = htri; h.blas = hblas;
+                    normal = hit_normal(T, h);
+                    ptri = htri; pu = hu; pv = hv;
+                    ro = add(ro, scale(nearest, rd));                                    // RK:129
+                    rd = normalize(reflect(rd, normal));                                 // RK:130
+                    sdir = normalize(sub(ro, sc.lightPos));                              // RK:147
+                    shadow = true;                                                       // RK:153
+                    start_ray();
+                }
+            } else if (st == ST_SDONE) {
+                ++nrays;
+                const float next = affect + sum;                                         // RK:120
+                const float distance = length(sdir);                                     // RK:148
+                const float intensity = light_term(sc, ro, normal, sdir, distance, htri >= 0, nearest);
+                const Albedo s = hit_albedo(T, ptri, pu, pv);
+                const v3 diffuseColor = scale(s.w, s.rgb);                               // RK:133
+                const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));    // RK:134
+                const v3 blended = scale(intensity, add(diffuseColor, samplerColor));    // RK:135
+                color = divs(add(scale(sum, color), scale(affect, blended)), next);      // RK:136
+                affect = affect / 2.0f;                                                  // RK:139
+                sum = next;                                                              // RK:140
+                ++bounce;
+                shadow = false;
+                if (bounce >= sc.bounces) finished = true;                               // RK:113
+                else start_ray();
+            }
+            // The sky.  FLAT (one colour): sampled here, along the missing ray (RK:123) and, for the fog colour of a finished pixel,
+            // along the primary ray (RK:92).  Textured: not sampled in this kernel at all -- the lane leaves the end-of-path
+            // record bvh_pixels leaves (rt_bvh.hip) and sky_resolve filters the cube map pixel per lane, full waves, neighbouring
+            // directions: same statements, same values, and no cube filter inside this kernel's register budget.
+            if (FLAT) {
+                if (missed) {
+                    const v3 sky = scale(sc.minIntensity, cube_sample<1>(A, rd));
+                    const float next = affect + sum;                                     // RK:120
+                    color = divs(add(scale(sum, color), scale(affect, sky)), next);      // RK:124
+                }
+                if (finished)
+                    reinterpret_cast<uint32_t*>(A.out)[opix] =
+                        compose_pixel_sky(scale(sc.minIntensity, cube_sample<1>(A, primary_dir(A, sc, xy & 0xFFFFu, xy >> 16))), color, dist);   // RK:91-98
+            } else if (finished) {
+                // dist is +0 or a hit distance > 0.001: its sign bit is free for the flag
+                A.fin[2u * opix] = make_float4(color.x, color.y, color.z, __uint_as_float(__float_as_uint(dist) | (missed ? 0x80000000u : 0u)));
+                if (missed && bounce != 0u) A.fin[2u * opix + 1u] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(bounce));
+            }
+            if (finished) st = ST_IDLE;
+            // ---- idle lanes take the next pixels of the frame ----
+            uint64_t idle = __ballot(st == ST_IDLE);
+            while (idle && !exhausted) {
+                if (cur == end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&A.qctrl[2], 64u);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total) { exhausted = true; break; }
+                    cur = base;
+                    end = min(base + 64u, total);
+                }
+                if ((cur & 63u) == 0u || cur == chunk_first) {       // entering a tile: decode it (wave-uniform)
+                    chunk_first = cur;
+                    chunk_ty = (cur >> 6) / tiles_x;
+                    chunk_tx = (cur >> 6) - chunk_ty * tiles_x;
+                }
+                const uint32_t tile_end = min(end, (cur & ~63u) + 64u);
+                const uint32_t take = min((uint32_t)__popcll(idle), tile_end - cur);
+                const uint32_t r = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (st == ST_IDLE && r < take) {
+                    const uint32_t l = (cur + r) & 63u;
+                    const uint32_t x = chunk_tx * 8u + (l & 7u), row = l >> 3;
+                    const uint32_t y = (A.tile_first + chunk_ty * A.tile_step) * 8u + row;
+                    if (x < A.W && y < A.H) {                        // RR:445: outside the texture: nothing
+                        opix = (chunk_ty * 8u + row) * A.W + x;
+                        xy = x | (y << 16);
+                        ro = sc.cameraPos; rd = primary_dir(A, sc, x, y);
+                        color = V(1.0f, 1.0f, 1.0f); dist = 0.0f;    // RK:102-103
+                        affect = 1.0f; sum = 0.0f; bounce = 0u;      // RK:106-107
+                        shadow = false;
+                        start_ray();
+                    }
+                }
+                cur += take;
+                idle = __ballot(st == ST_IDLE);
+            }
+        }
+    }
+#ifdef RT_FLOW_COUNT
+    if (lane == 0u) {
+        for (int k = 0; k < 4; ++k) { atomicAdd(&g_flow_count[2 * k], (unsigned long long)c_runs[k]); atomicAdd(&g_flow_count[2 * k + 1], (unsigned long long)c_lanes[k]); }
+        atomicAdd(&g_flow_count[8], (unsigned long long)c_trips);
+    }
+    atomicAdd(&g_flow_count[9], (unsigned long long)c_lds);
+#endif
+    count_rays(A.rays, nrays);
+}
+
+}  // namespace rtk
+
+#ifdef RT_FLOW_COUNT
+extern "C" __attribute__((visibility("default"))) int rt_debug_flow_counts(unsigned long long* dst, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(rtk::g_flow_count), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && clear) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(rtk::g_flow_count), z, sizeof z);
+    }
+    return (int)e;
+}
+#endif
+
+size_t rt_flow_lds_bytes(uint32_t waves, uint32_t lds_pairs) {
+    return (size_t)2u * rtk::kLdsNodes * 16u + 20u * kFlowInst * 4u + (size_t)kFlowKB * 64u * waves * 4u + (size_t)kFlowKT * 64u * waves * 2u +
+           (size_t)lds_pairs * 64u;
+}
+
+// Pair records a workgroup of `waves` waves stages when `per_cu` such workgroups share a CU's 160 KB (handed out in 1280-byte granules).
+uint32_t rt_flow_lds_pairs(uint32_t waves, uint32_t per_cu, uint32_t n_pairs) {
+    const size_t granules = 128u / per_cu;
+    const size_t room = granules * 1280u;
+    const size_t fixed = rt_flow_lds_bytes(waves, 0u);
+    if (room <= fixed) return 0u;
+    const size_t k = (room - fixed) / 64u;
+    return (uint32_t)(k < n_pairs ? k : n_pairs);
+}
+
+template <int WAVES>
+static hipError_t launch_flow_as(const RtFrameArgs& a, const RtTriScene& t, RtFlowArgs f, uint32_t per_cu, uint32_t blocks, hipStream_t s) {
+    f.lds_pairs = rt_flow_lds_pairs(WAVES, per_cu, f.n_pairs);
+    const size_t lds = rt_flow_lds_bytes(WAVES, f.lds_pairs);
+    auto k = a.sky_flat ? rtk::trace_flow<WAVES, true> : rtk::trace_flow<WAVES, false>;
+    if (lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (!a.sky_flat && !a.fin) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a, t, f);
+    if (!a.sky_flat) return rt_launch_sky_resolve(a, s);
+    return hipGetLastError();
+}
+
+// waves: waves per workgroup (16 / 8 / 4); per_cu: workgroups of this frame's launch sized to share a CU.
+hipError_t rt_launch_flow(const RtFrameArgs& a, const RtTriScene& t, const RtFlowArgs& f, uint32_t waves, uint32_t per_cu, uint32_t blocks, hipStream_t s) {
+    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    g_rt_kernel_id = RT_KID_TRIANGLES_FLOW;
+    if (waves == 16u) return launch_flow_as<16>(a, t, f, per_cu, blocks, s);
+    if (waves == 8u) return launch_flow_as<8>(a, t, f, per_cu, blocks, s);
+    return launch_flow_as<4>(a, t, f, per_cu, blocks, s);
+}

@@ -103,6 +103,7 @@ hipError_t rt_launch_frame_epilogue(unsigned long long* counters, unsigned long 
 hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
 hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s);
+hipError_t rt_launch_sky_resolve(const RtFrameArgs& a, hipStream_t s);   // textured sky: composes the end-of-path records in a.fin (rt_bvh.hip)
 hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, hipStream_t s);
 hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t W, uint32_t H,

@@ -64,7 +64,8 @@ typedef enum rt_kernel_id {
     RT_KID_HIERARCHY_16 = 6,     /* 16-wave workgroups, one per CU */
     RT_KID_HIERARCHY_GLOBAL = 7, /* nodes read from global memory (scenes beyond a CU's LDS) */
     RT_KID_TRIANGLES = 8,        /* trace_triangles (TLAS / BLAS traversal) */
-    RT_KID_HEATMAP = 9           /* heatmap_triangles */
+    RT_KID_HEATMAP = 9,          /* heatmap_triangles */
+    RT_KID_TRIANGLES_FLOW = 10   /* trace_flow: persistent waves, one traversal step per trip, BLAS heads in LDS (rt_flow.hip) */
 } rt_kernel_id;
 
 typedef enum rt_kernel {
@@ -179,7 +180,9 @@ int rt_set_mode(rt_ctx* ctx, int mode);
  * 0 = bounding-sphere hierarchy from 128 spheres on (from 72 on once the caller keeps frames in flight), single
  * brute-force kernel below;
  * 4 = hierarchy for any sphere count; 5 = brute force (two-kernel pipeline from 320 spheres on);
- * 1, 2, 3 = individual brute-force forms.  Every variant produces the same pixels.  See DESIGN.md. */
+ * 1, 2, 3 = individual brute-force forms.  Triangle scenes: 0 = the persistent kernel (rt_flow.hip) for scenes of up to
+ * 16 instances whose node buffer and lookup table fit 16-bit indices, the tile-per-wave kernel (rt_triangles.hip) otherwise;
+ * 6 = the tile-per-wave kernel always.  Every variant produces the same pixels.  See DESIGN.md. */
 int rt_set_variant(rt_ctx* ctx, int variant);
 
 /* ---- multi-GPU partition --------------------------------------------------------------- */
@@ -311,6 +314,16 @@ int rt_group_wait(rt_group* g);
  * when cap_nodes < n_nodes + 1 (*n_nodes is set either way; at most 2 n + 64 nodes). */
 int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* link, uint32_t cap_nodes,
                        uint32_t* n_nodes);
+
+/* Runs the HOST side of the persistent triangle kernel on its own (no device, no context): the relinked copy of the BLAS
+ * trees it walks.  `nodes`: the node buffer as rt_write_nodes receives it (8 f32 per node); `roots`: the
+ * rootNodeIndex of every instance.  Writes *n_pairs records of 16 words {c1.min.xyz, meta1, c1.max.xyz, 0, c2.min.xyz, meta2,
+ * c2.max.xyz, 0} -- the two children of an inner node, meta = primitiveCount << 16 | x with x = the leaf's first lookup
+ * slot or the inner child's own record number -- ordered most-visited first (by the surface area of the parent's box), and
+ * per root its meta.  RT_ERR_UNSUPPORTED for a node buffer beyond 65,536 entries or a primitiveCount beyond 65,535 (such scenes
+ * are rendered by the tile-per-wave kernel), RT_ERR_CAPACITY when cap_pairs < *n_pairs (*n_pairs is set either way). */
+int rt_build_flow(const float* nodes, uint32_t n_nodes, const uint32_t* roots, uint32_t n_roots, float* pairs, uint32_t cap_pairs,
+                  uint32_t* n_pairs, uint32_t* root_meta);
 
 /* Which filter forms a frame of this scene may use (no device needed): *filter_ok = 0 when
  * max(|center| + |radius| over the spheres, |cameraPos|, |lightPosition|) is NaN, infinite or

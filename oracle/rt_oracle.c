@@ -74,6 +74,11 @@ typedef struct {
 
 static render_state trace_tlas(const rt_oracle_tri_scene* T, v3 o, v3 d, uint32_t* steps);
 static void tri_work_flush(void);
+/* measurement only (rt_oracle_tri_trace_px): the sequence of traversal steps of the current pixel, one byte each */
+static uint64_t g_sp_hist[2][24];   /* measurement only: pushes by stack slot, [0] BLAS [1] TLAS (racy under OpenMP; use 1 thread) */
+static uint32_t* g_node_hist;   /* measurement only: visits per inner BLAS node (single-threaded use) */
+static __thread uint8_t* tl_trace; static __thread size_t tl_trace_n, tl_trace_cap;
+static inline void trace_code(uint8_t c) { if (tl_trace) { if (tl_trace_n < tl_trace_cap) tl_trace[tl_trace_n] = c; ++tl_trace_n; } }
 static v3 tex2d_sample(const rt_oracle_face* f, float u, float v);
 
 /* ---- HK:307-331 hitSphere ------------------------------------------------ */
@@ -276,7 +281,7 @@ static float light_intensity(const scene_params* sc, const oscene* S,
     v3 direction = normalize(sub(destination, sc->lightPos));    /* RK:147 */
     float distance = length(direction);                          /* RK:148 (quirk: ~1) */
     render_state result = trace_scene(S, sc->lightPos, direction); /* RK:150-153 */
-    *rays += 1;
+    *rays += 1; trace_code('S');
     if (result.hit) {                                            /* RK:155 */
         v3 hitPoint = add(sc->lightPos, scale(result.t, direction)); /* RK:156 */
         float diff = length(sub(hitPoint, destination));         /* RK:157 */
@@ -305,7 +310,7 @@ static void ray_color(const scene_params* sc, const oscene* S,
     float affectFactor = 1.0f, sumFactor = 0.0f;                 /* RK:111-112 */
     for (uint32_t bounce = 0; bounce < bounces; ++bounce) {      /* RK:113 */
         render_state result = trace_scene(S, ro, rd);            /* RK:114 */
-        *rays += 1;
+        *rays += 1; trace_code('R');
         if (bounce == 0) dist = result.t;                        /* RK:116-118 */
         float nextSumFactor = affectFactor + sumFactor;          /* RK:120 */
         if (!result.hit) {                                       /* RK:122 */
@@ -513,6 +518,8 @@ typedef struct { v3 minCorner; float leftChildIndex; v3 maxCorner; float primiti
  * the totals row by row; rt_oracle_tri_counters reads and clears the totals. */
 static __thread uint64_t tl_tri_work[3];
 static uint64_t g_tri_work[3];
+/* per-thread, never flushed: BLAS inner-node visits, BLAS leaf visits (rt_oracle_tri_work_px reads differences) */
+static __thread uint64_t tl_tri_visits[2];
 static void tri_work_flush(void) {
     for (int k = 0; k < 3; ++k) {
         if (tl_tri_work[k]) __atomic_fetch_add(&g_tri_work[k], tl_tri_work[k], __ATOMIC_RELAXED);
@@ -594,7 +601,7 @@ static inline render_state hit_triangle(v3 o, v3 d, const float* tri, float tMin
 static render_state trace_blas(const rt_oracle_tri_scene* T, v3 o, v3 d, const float* blas,
                                float nearestHit, const render_state* renderState, uint32_t* steps) {
     const float* m = blas;   /* m[4*c + r] */
-    tl_tri_work[2] += 1;
+    tl_tri_work[2] += 1; trace_code('I');
     /* mat4x4 * vec4: sum over columns, left to right (RK:254-255) */
     v3 oo = V(((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.0f,
               ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.0f,
@@ -614,6 +621,8 @@ static render_state trace_blas(const rt_oracle_tri_scene* T, v3 o, v3 d, const f
         uint32_t primitiveCount = u32f(node.primitiveCount);                     /* RK:272 */
         uint32_t leftChildNodeIndex = u32f(node.leftChildIndex);                 /* RK:273 */
         if (primitiveCount == 0) {                                               /* RK:275 */
+            tl_tri_visits[0] += 1; trace_code('N');
+            if (g_node_hist && leftChildNodeIndex < T->n_nodes) g_node_hist[leftChildNodeIndex] += 1;
             if (steps) *steps += 2;                                              /* HK:242 */
             uint32_t iChild1 = leftChildNodeIndex, iChild2 = leftChildNodeIndex + 1u;
             bvh_node c1 = load_node(T, leftChildNodeIndex), c2 = load_node(T, leftChildNodeIndex + 1u);
@@ -631,10 +640,12 @@ static render_state trace_blas(const rt_oracle_tri_scene* T, v3 o, v3 d, const f
                 node = load_node(T, iChild1);                                    /* RK:302 */
                 if (distance2 < blasNearestHit) {                                /* RK:303 */
                     stack[sclamp(stackLocation)] = iChild2;                      /* RK:304 (no overflow guard) */
+                    g_sp_hist[0][stackLocation < 23u ? stackLocation : 23u] += 1;
                     stackLocation += 1;
                 }
             }
         } else {
+            tl_tri_visits[1] += 1;
             for (uint32_t i = 0; i < primitiveCount; ++i) {                      /* RK:311 */
                 uint32_t li = i + leftChildNodeIndex;
                 if (li >= T->n_tri_lookup) li = T->n_tri_lookup - 1u;
@@ -642,7 +653,7 @@ static render_state trace_blas(const rt_oracle_tri_scene* T, v3 o, v3 d, const f
                 if (ti >= T->n_triangles) ti = T->n_triangles - 1u;
                 render_state ns = hit_triangle(oo, od, T->triangles + 40u * (size_t)ti, 0.001f,
                                                blasNearestHit, &brs);            /* RK:312-316 */
-                tl_tri_work[1] += 1;
+                tl_tri_work[1] += 1; trace_code('T');
                 if (steps) *steps += 1;                                          /* HK:279 */
                 if (ns.hit) { blasNearestHit = ns.t; brs = ns; }                 /* RK:318-321 */
             }
@@ -673,6 +684,7 @@ static render_state trace_tlas(const rt_oracle_tri_scene* T, v3 o, v3 d, uint32_
         uint32_t modelCount = u32f(node.primitiveCount);                         /* RK:180 */
         uint32_t leftChildNodeIndex = u32f(node.leftChildIndex);                 /* RK:181 */
         if (modelCount == 0) {                                                   /* RK:183 */
+            trace_code('n');
             if (steps) *steps += 2;                                              /* HK:143 */
             uint32_t iChild1 = leftChildNodeIndex, iChild2 = leftChildNodeIndex + 1u;
             bvh_node c1 = load_node(T, leftChildNodeIndex), c2 = load_node(T, leftChildNodeIndex + 1u);
@@ -690,6 +702,7 @@ static render_state trace_tlas(const rt_oracle_tri_scene* T, v3 o, v3 d, uint32_
                 node = load_node(T, iChild1);                                    /* RK:208 */
                 if (distance2 < nearestHit) {                                    /* RK:209 */
                     stack[sclamp(stackLocation)] = iChild2;
+                    g_sp_hist[1][stackLocation < 23u ? stackLocation : 23u] += 1;
                     stackLocation += 1;
                     /* RK:212-214 guards with `>`; the heatmap twin (steps != NULL) with `>=`, HK:168 */
                     if (steps ? stackLocation >= STACK_SIZE : stackLocation > STACK_SIZE) stackLocation = STACK_SIZE - 1u;
@@ -738,6 +751,55 @@ static v3 tex2d_sample(const rt_oracle_face* f, float u, float v) {
  * Its traversal arithmetic is RK's; its struct declarations differ (no light fields HK:1-7,
  * rootNodeIndex as vec4 HK:29-32, colour vec3 HK:19) but read the same bytes of the shared
  * buffers. */
+
+/* Measurement only (tools/tri_path_stats.py): the work of every pixel's path over the triangle scene, out_px[4 * (y*W+x)]
+ * = {scene traversals, BLAS inner-node visits, triangle tests, instance records read}.  Single-threaded. */
+int rt_oracle_tri_work_px(const float params[24], const rt_oracle_tri_scene* tri, const rt_oracle_face faces[6],
+                          uint32_t W, uint32_t H, uint32_t* out_px) {
+    if (!tri || !tri->nodes || tri->n_nodes == 0 || !tri->mesh_tex.rgba || !out_px) return -1;
+    scene_params sc = unpack(params);
+    oscene S = {NULL, 0, tri};
+    for (uint32_t y = 0; y < H; ++y)
+        for (uint32_t x = 0; x < W; ++x) {
+            float rgb[3];
+            uint64_t rays = 0;
+            const uint64_t v0 = tl_tri_visits[0], t0 = tl_tri_work[1], i0 = tl_tri_work[2];
+            shade_pixel(&sc, &S, faces, W, H, x, y, rgb, &rays);
+            uint32_t* o = out_px + 4u * ((size_t)y * W + x);
+            o[0] = (uint32_t)rays; o[1] = (uint32_t)(tl_tri_visits[0] - v0);
+            o[2] = (uint32_t)(tl_tri_work[1] - t0); o[3] = (uint32_t)(tl_tri_work[2] - i0);
+        }
+    tri_work_flush();
+    return 0;
+}
+
+
+/* Measurement only (tools/tri_sched_sim.py): the step sequence of every pixel's path, one byte per step -- 'n' TLAS inner
+ * node, 'I' instance entered, 'N' BLAS inner node, 'T' triangle test, 'R' / 'S' reflection / shadow ray complete --,
+ * pixel p's steps at codes[offsets[p] .. offsets[p+1]).  Returns the number of bytes needed (codes may be too small). */
+void rt_oracle_tri_sp_hist(uint64_t out[48]) { memcpy(out, g_sp_hist, sizeof g_sp_hist); memset(g_sp_hist, 0, sizeof g_sp_hist); }
+void rt_oracle_tri_node_hist(uint32_t* hist) { g_node_hist = hist; }   /* hist[left child index] += 1 per inner-node visit; NULL: off */
+
+uint64_t rt_oracle_tri_trace_px(const float params[24], const rt_oracle_tri_scene* tri, const rt_oracle_face faces[6],
+                                uint32_t W, uint32_t H, uint8_t* codes, uint64_t cap, uint64_t* offsets) {
+    scene_params sc = unpack(params);
+    oscene S = {NULL, 0, tri};
+    uint64_t at = 0;
+    for (uint32_t y = 0; y < H; ++y)
+        for (uint32_t x = 0; x < W; ++x) {
+            float rgb[3];
+            uint64_t rays = 0;
+            offsets[(size_t)y * W + x] = at;
+            tl_trace = codes ? codes + (at < cap ? at : cap) : (uint8_t*)&rays; tl_trace_n = 0; tl_trace_cap = codes && at < cap ? cap - at : 0;
+            shade_pixel(&sc, &S, faces, W, H, x, y, rgb, &rays);
+            at += tl_trace_n;
+        }
+    offsets[(size_t)W * H] = at;
+    tl_trace = NULL;
+    tri_work_flush();
+    return at;
+}
+
 int rt_oracle_heatmap_tri(const float params[24], const rt_oracle_tri_scene* tri, uint32_t W, uint32_t H,
                           uint8_t* out_rgba8, uint32_t* out_steps, int threads) {
     if (!params || !tri || !tri->nodes || tri->n_nodes == 0) return -1;

@@ -137,6 +137,22 @@ int rt_oracle_trace_tri_rays(const rt_oracle_tri_scene* tri, uint32_t n, const f
  * triangle tests, out[2] 80-B instance records.  Reading clears.  Measurement only (bench.py --config TRI). */
 void rt_oracle_tri_counters(uint64_t out[3]);
 
+/* Measurement only: per pixel {scene traversals, BLAS inner-node visits, triangle tests, instance records read}
+ * of the path RK:73-166 traces over the triangle scene (out_px: W*H*4 words).  Single-threaded. */
+int rt_oracle_tri_work_px(const float params[24], const rt_oracle_tri_scene* tri, const rt_oracle_face faces[6],
+                          uint32_t W, uint32_t H, uint32_t* out_px);
+
+/* Measurement only: every pixel's sequence of traversal steps, one byte each ('n' TLAS inner node, 'I' instance entered,
+ * 'N' BLAS inner node, 'T' triangle test, 'R' / 'S' reflection / shadow ray complete); pixel p's at
+ * codes[offsets[p] .. offsets[p+1]) (offsets: W*H+1 entries).  Returns the bytes needed.  Single-threaded. */
+uint64_t rt_oracle_tri_trace_px(const float params[24], const rt_oracle_tri_scene* tri, const rt_oracle_face faces[6],
+                                uint32_t W, uint32_t H, uint8_t* codes, uint64_t cap, uint64_t* offsets);
+
+/* Measurement only: while `hist` is set, every BLAS inner-node visit adds 1 to hist[left child index] (n_nodes words). */
+void rt_oracle_tri_node_hist(uint32_t* hist);
+/* Measurement only: pushes by stack slot since the last call, out[0..23] traceBLAS, out[24..47] traceTLAS (slot 23: beyond). */
+void rt_oracle_tri_sp_hist(uint64_t out[48]);
+
 int rt_oracle_max_threads(void);
 
 #ifdef __cplusplus

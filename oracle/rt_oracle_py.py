@@ -244,3 +244,36 @@ def trace_tri_rays(buffers, origins, dirs, want_tri=False):
 
 def max_threads():
     return lib().rt_oracle_max_threads()
+
+
+def tri_work_px(params, buffers, faces, W, H):
+    """Measurement only: (H, W, 4) uint32 per pixel {scene traversals, BLAS inner-node visits, triangle tests,
+    instance records read} of the path over a triangle scene (single-threaded)."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    t, keep = _tri_scene(buffers)
+    arr, keepf = _faces(faces)
+    out = np.zeros((H, W, 4), dtype=np.uint32)
+    L = lib()
+    L.rt_oracle_tri_work_px.restype = ctypes.c_int
+    L.rt_oracle_tri_work_px.argtypes = [ctypes.c_void_p, ctypes.POINTER(_TriScene), ctypes.POINTER(_Face),
+                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    rc = L.rt_oracle_tri_work_px(_fp(params), ctypes.byref(t), arr, W, H, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("rt_oracle_tri_work_px failed: %d" % rc)
+    return out
+
+
+def tri_trace_px(params, buffers, faces, W, H):
+    """Measurement only: (codes uint8 array, offsets uint64 array of W*H+1) -- the step sequence of every pixel's path."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    t, keep = _tri_scene(buffers)
+    arr, keepf = _faces(faces)
+    L = lib()
+    L.rt_oracle_tri_trace_px.restype = ctypes.c_uint64
+    L.rt_oracle_tri_trace_px.argtypes = [ctypes.c_void_p, ctypes.POINTER(_TriScene), ctypes.POINTER(_Face), ctypes.c_uint32,
+                                         ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    offs = np.zeros(W * H + 1, dtype=np.uint64)
+    need = L.rt_oracle_tri_trace_px(_fp(params), ctypes.byref(t), arr, W, H, None, 0, offs.ctypes.data)
+    codes = np.zeros(int(need), dtype=np.uint8)
+    L.rt_oracle_tri_trace_px(_fp(params), ctypes.byref(t), arr, W, H, codes.ctypes.data, need, offs.ctypes.data)
+    return codes, offs

@@ -50,10 +50,12 @@ def diff_stats(a, b):
 from compute_raytracer_amd.procedural import obj_floor, obj_uv_sphere, tri_buffers, triangle_scene  # noqa: E402,F401
 
 
-def gpu_render_tri(scene, material, width, height, bounces, skybox=None, heatmap=False):
+def gpu_render_tri(scene, material, width, height, bounces, skybox=None, heatmap=False, variant=0):
+    """variant 0: the library's choice (the persistent kernel where the scene fits it), 6: the tile-per-wave kernel."""
     import compute_raytracer_amd as rt
     r = rt.RendererRaytracing(width, height, scene, maxBounces=bounces)
     r.initialize(skybox, material)
+    r.set_variant(variant)
     if heatmap:
         r.showHeatmap()
     r.render()

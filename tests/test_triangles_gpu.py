@@ -22,33 +22,42 @@ def random_sky(seed, w=8, h=8):
     return m
 
 
+# both kernels of the triangle path: 0 = the library's choice (the persistent kernel, rt_flow.hip: these scenes fit it),
+# 6 = the tile-per-wave kernel (rt_triangles.hip)
+KERNELS = {0: "triangles_flow", 6: "triangles"}
+
+
+@pytest.mark.parametrize("variant", [0, 6])
 @pytest.mark.parametrize("seed,W,H,B", [(1, 320, 200, 4), (2, 333, 207, 2), (3, 64, 64, 8), (4, 8, 8, 1), (5, 200, 120, 0)])
-def test_triangle_scene_bit_exact(oracle, seed, W, H, B):
+def test_triangle_scene_bit_exact(oracle, seed, W, H, B, variant):
     scene, mat = triangle_scene(seed=seed, n_models=3)
     sky = random_sky(seed)
     ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
-    img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky)
+    img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky, variant=variant)
     assert np.array_equal(img, ref), diff_stats(img, ref)
-    assert st["rays"] == rays
+    assert st["rays"] == rays and abi.KERNEL_IDS[st["kernel_id"]] == KERNELS[variant]
 
 
-def test_finer_meshes_deeper_trees(oracle):
+@pytest.mark.parametrize("variant", [0, 6])
+def test_finer_meshes_deeper_trees(oracle, variant):
     scene, mat = triangle_scene(seed=7, n_models=5, rings=24, sectors=32)
     assert scene.triangleCount > 3000
     sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
     ref, _, rays = oracle.render_tri(scene.pack_params(4), tri_buffers(scene, mat), sky.faces, 480, 270)
-    img, st = gpu_render_tri(scene, mat, 480, 270, 4, skybox=sky)
+    img, st = gpu_render_tri(scene, mat, 480, 270, 4, skybox=sky, variant=variant)
     assert np.array_equal(img, ref), diff_stats(img, ref)
-    assert st["rays"] == rays
+    assert st["rays"] == rays and abi.KERNEL_IDS[st["kernel_id"]] == KERNELS[variant]
 
 
-def test_animation_loop_rebuilds_tlas_each_frame(oracle):
+@pytest.mark.parametrize("variant", [0, 6])
+def test_animation_loop_rebuilds_tlas_each_frame(oracle, variant):
     """src/app.ts:117-128: scene.update(dt) (models spin, TLAS + BLAS matrices rebuilt, SR:138-143),
     camera.move, renderer.render: per frame only params, BLAS records, BLAS lookup and TLAS nodes
     are re-uploaded (RR:157-192)."""
     scene, mat = triangle_scene(seed=9, n_models=3)
     sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
     r = rt.RendererRaytracing(240, 136, scene, maxBounces=3).initialize(sky, mat)
+    r.set_variant(variant)
     try:
         for frame in range(3):
             scene.update(0.25)
@@ -187,8 +196,10 @@ def test_large_instance_sets_and_whole_buffer_node_writes(oracle):
         r.close()
 
 
-def test_tile_order_does_not_change_the_picture(oracle):
-    """From 4096 tiles on the triangle kernel starts a frame's tiles longest-first, in the order the previous frame on the
+@pytest.mark.parametrize("variant", [0, 6])
+def test_tile_order_does_not_change_the_picture(oracle, variant):
+    """(variant 0: the same frames through the persistent kernel, whose lanes take pixels from a cursor.)
+    From 4096 tiles on the triangle kernel starts a frame's tiles longest-first, in the order the previous frame on the
     same stream suggests (rt_triangles.hip: order_tiles).  1024 x 516 = 8320 tiles, ragged last row; the camera walks and
     the models spin, so every frame is rendered in an order made for another picture: ten frames one at a time (each of
     the four streams comes round at least twice), then six in flight, each against the oracle."""
@@ -196,6 +207,7 @@ def test_tile_order_does_not_change_the_picture(oracle):
     scene, mat = triangle_scene(seed=21, n_models=3)
     sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
     r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+    r.set_variant(variant)
     try:
         for frame in range(10):
             scene.update(0.2)
@@ -242,3 +254,51 @@ def test_scenes_beyond_the_packed_stack_take_the_index_stack(oracle, heatmap):
         img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky)
         assert st["rays"] == rays
     assert np.array_equal(img, ref), diff_stats(img, ref)
+
+
+def spine_scene(depth):
+    """A BLAS no builder would make: a spine of `depth` inner nodes, each with a leaf as its FARTHER child, so that the
+    walk pushes one entry per level -- beyond the eight slots the persistent kernel keeps in LDS, and beyond the twenty the
+    reference's stack has at all (RK:71; RK:303-306 pushes without a guard: the index clamps to the last slot, and the pops
+    that follow read that slot again and again).  One triangle per leaf, each covering its own part of the view."""
+    base = 1                                                    # tlasNodesMax of one instance
+    nodes = np.zeros((1 + 2 * depth, 8), np.float32)            # S_0, then the pairs (A_k, S_{k+1}); the last "S" is a leaf
+    tris = np.zeros((depth + 1, 40), np.float32)
+    def box(i, lo, hi, left, count):
+        nodes[i, 0:3] = lo; nodes[i, 3] = left; nodes[i, 4:7] = hi; nodes[i, 7] = count
+    box(0, [-9, -9, -1.0], [9, 9, 5.0], base + 1, 0)
+    for k in range(depth):
+        a, s = 1 + 2 * k, 2 + 2 * k
+        box(a, [-9, -9, -3.0], [9, 9, -2.0], k, 1)                                   # leaf A_k: lookup slot k
+        if k + 1 < depth: box(s, [-9, -9, -1.0], [9, 9, 5.0], base + s + 1, 0)       # S_{k+1}
+        else: box(s, [-9, -9, -1.0], [9, 9, 5.0], depth, 1)                          # the bottom: a leaf inside the near box
+    for k in range(depth + 1):
+        z = -2.05 - 0.9 * k / depth if k < depth else -0.5
+        x0 = -8.0 + 16.0 * ((k * 7) % (depth + 1)) / (depth + 1)
+        w = 3.0 if k < depth else 40.0
+        # front face towards +z (RK:359 culls det < 1e-5)
+        for c, (x, y) in enumerate([(x0, -8.0), (x0 + w, -8.0), (x0 + w / 2, 9.0)]):
+            tris[k, 12 * c:12 * c + 3] = [x, y, z]
+            tris[k, 12 * c + 4:12 * c + 7] = [0, 0, 1]
+            tris[k, 12 * c + 8:12 * c + 10] = [c / 2.0, c % 2]
+        tris[k, 36:40] = [0.2 + 0.8 * ((k * 5) % 7) / 7.0, 0.3 + 0.7 * ((k * 3) % 5) / 5.0, 0.9 - 0.6 * (k % 4) / 4.0, 1.0 if k % 3 else 0.5]
+    d = dict(triangles=tris, blas_nodes=nodes, tri_lookup=np.arange(depth + 1, dtype=np.float32),
+             mesh_root=np.array([base]), mesh_box_lo=np.array([[-9.0, -9.0, -3.0]]), mesh_box_hi=np.array([[9.0, 9.0, 5.0]]),
+             inst_mesh=np.array([0]), inst_position=np.array([[0.0, 0.0, 0.0]]), inst_eulers=np.array([[0.0, 0.0, 0.0]]),
+             inst_speed=np.array([[0.0, 0.0, 0.0]]), camera_position=np.array([0.0593, 2.692, 3.293]),
+             camera_eulers=np.array([0.0, 106.0, 270.0], np.float32), light=np.array([0.0, 5.0, 6.0, 3.0, 0.3]))
+    return rt.SceneRaytracing.from_packed(d)
+
+
+@pytest.mark.parametrize("variant", [0, 6])
+@pytest.mark.parametrize("depth", [7, 12, 19, 20, 21, 33])
+def test_stack_depth_beyond_the_lds_slots_and_beyond_the_reference_stack(oracle, depth, variant):
+    scene = spine_scene(depth)
+    mat = rt.Material(np.random.default_rng(depth).integers(0, 256, (8, 8, 4), dtype=np.uint8))
+    sky = random_sky(depth)
+    W, H, B = 160, 96, 3
+    ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
+    assert len(np.unique(ref.reshape(-1, 4), axis=0)) > 20           # the spine is in view
+    img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky, variant=variant)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays and abi.KERNEL_IDS[st["kernel_id"]] == KERNELS[variant]
