@@ -39,6 +39,30 @@ enum : uint32_t { ST_IDLE = 0u, ST_TLAS = 1u, ST_BNODE = 2u, ST_TRI = 3u, ST_RDO
 __device__ unsigned long long g_flow_count[16];
 #endif
 
+// LDS is addressed explicitly (address space 3, byte addresses): a pointer that may name LDS or global memory -- "the pair
+// record, wherever it lives", "the stack slot, LDS or overflow" -- makes the compiler emit FLAT loads for both, which
+// serialise through the address-aperture check; with typed pointers the two sides are ds_read and global_load under their
+// own exec masks.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f4v* lds_f4;
+typedef __attribute__((address_space(3))) const float* lds_f32;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+typedef __attribute__((address_space(3))) uint16_t* lds_u16;
+__device__ __forceinline__ float4 lds_read4(uint32_t a) { const f4v v = *(lds_f4)(uintptr_t)a; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float lds_read1(uint32_t a) { return *(lds_f32)(uintptr_t)a; }
+
+// node i of the node buffer: from the staged head (LDS byte address a_nodes, n_head nodes) or from global memory; RK:175 etc.
+__device__ __forceinline__ NodeR flow_node(const RtTriScene& T, uint32_t a_nodes, uint32_t n_head, uint32_t i) {
+    if (i >= T.n_nodes) i = T.n_nodes - 1u;
+    float4 a, b;
+    if (i < n_head) { a = lds_read4(a_nodes + 32u * i); b = lds_read4(a_nodes + 32u * i + 16u); }
+    else { a = T.nodes[2u * (size_t)i]; b = T.nodes[2u * (size_t)i + 1u]; }
+    NodeR n;
+    n.lo = V(a.x, a.y, a.z); n.left = a.w;
+    n.hi = V(b.x, b.y, b.z); n.count = b.w;
+    return n;
+}
+
 __device__ __forceinline__ uint32_t pack_node(const NodeR& n) {
     const uint32_t c = u32f(n.count), l = u32f(n.left);
     return ((c < 0xFFFFu ? c : 0xFFFFu) << 16) | (l < 0xFFFFu ? l : 0xFFFFu);
@@ -68,15 +92,18 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A,
         s_blas[i] = v;
     }
     {
+        // quarter-major in LDS ([quarter][pair], 16-byte stride within a quarter): lanes reading the same quarter of DIFFERENT
+        // records -- what a step does -- spread over all banks; record-major, every lane's 16 bytes would start at bank 0 or 16
         float4* const dst = const_cast<float4*>(s_pairs);
-        for (uint32_t i = threadIdx.x; i < 4u * F.lds_pairs; i += stride) dst[i] = F.pairs[i];
+        for (uint32_t i = threadIdx.x; i < 4u * F.lds_pairs; i += stride) dst[(i & 3u) * F.lds_pairs + (i >> 2)] = F.pairs[i];
     }
     __syncthreads();
     L.nodes = s_nodes; L.blas = s_blas;
+    // LDS byte addresses of the staged arrays (the low word of a pointer into the LDS aperture is the LDS address)
+    const uint32_t a_nodes = (uint32_t)(uintptr_t)s_nodes, a_blas = (uint32_t)(uintptr_t)s_blas, a_pairs = (uint32_t)(uintptr_t)s_pairs;
+    const uint32_t a_bst = (uint32_t)(uintptr_t)(s_bstack + threadIdx.x), a_tst = (uint32_t)(uintptr_t)(s_tstack + threadIdx.x);
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* const bst = s_bstack + threadIdx.x;
-    uint16_t* const tst = s_tstack + threadIdx.x;
     // overflow stacks of this wave: [kStack - kFlowKB][64] words, then [kStack - kFlowKT][64] half words
     uint32_t* const ovf_b = F.ovf + (size_t)(blockIdx.x * WAVES + wave) * kFlowOvfWords + lane;
     uint16_t* const ovf_t = reinterpret_cast<uint16_t*>(F.ovf + (size_t)(blockIdx.x * WAVES + wave) * kFlowOvfWords + (kStack - kFlowKB) * 64u) + lane;
@@ -88,7 +115,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A,
     uint32_t chunk_ty = 0, chunk_tx = 0, chunk_first = ~0u;
     bool exhausted = false;
     // the ray every path starts with enters the TLAS at node 0 (RK:175): its (count, left), once per wave
-    const uint32_t root_tnode = pack_node(load_node_head(T, L, 0u));
+    const uint32_t root_tnode = pack_node(flow_node(T, a_nodes, L.n_nodes, 0u));
 
     // ---- per-lane state ----
     uint32_t st = ST_IDLE;
@@ -133,10 +160,26 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A,
 #endif
 
     // one hybrid-stack access: slot s of this lane, LDS below the split, the wave's overflow area above
-    auto bpush = [&](uint32_t s, uint32_t v) { if (s < kFlowKB) bst[s * stride] = v; else ovf_b[(s - kFlowKB) * 64u] = v; };
-    auto bread = [&](uint32_t s) -> uint32_t { return s < kFlowKB ? bst[s * stride] : ovf_b[(s - kFlowKB) * 64u]; };
-    auto tpush = [&](uint32_t s, uint32_t v) { if (s < kFlowKT) tst[s * stride] = (uint16_t)v; else ovf_t[(s - kFlowKT) * 64u] = (uint16_t)v; };
-    auto tread = [&](uint32_t s) -> uint32_t { return s < kFlowKT ? (uint32_t)tst[s * stride] : (uint32_t)ovf_t[(s - kFlowKT) * 64u]; };
+    auto bpush = [&](uint32_t s, uint32_t v) {
+        if (s < kFlowKB) *(lds_u32)(uintptr_t)(a_bst + s * (stride * 4u)) = v;
+        else ovf_b[(s - kFlowKB) * 64u] = v;
+    };
+    auto bread = [&](uint32_t s) -> uint32_t {
+        uint32_t v;
+        if (s < kFlowKB) v = *(lds_u32)(uintptr_t)(a_bst + s * (stride * 4u));
+        else v = ovf_b[(s - kFlowKB) * 64u];
+        return v;
+    };
+    auto tpush = [&](uint32_t s, uint32_t v) {
+        if (s < kFlowKT) *(lds_u16)(uintptr_t)(a_tst + s * (stride * 2u)) = (uint16_t)v;
+        else ovf_t[(s - kFlowKT) * 64u] = (uint16_t)v;
+    };
+    auto tread = [&](uint32_t s) -> uint32_t {
+        uint32_t v;
+        if (s < kFlowKT) v = (uint32_t)*(lds_u16)(uintptr_t)(a_tst + s * (stride * 2u));
+        else v = (uint32_t)ovf_t[(s - kFlowKT) * 64u];
+        return v;
+    };
 
     // a new ray of this lane's path enters the TLAS (RK:170-178)
     auto start_ray = [&]() {
@@ -182,7 +225,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A,
                 const uint32_t p = bnode & 0xFFFFu;
                 float4 q0, q1, q2, q3;
                 if (p < F.lds_pairs) {
-                    q0 = s_pairs[4u * p]; q1 = s_pairs[4u * p + 1u]; q2 = s_pairs[4u * p + 2u]; q3 = s_pairs[4u * p + 3u];
+                    const uint32_t a = a_pairs + 16u * p, q = 16u * F.lds_pairs;
+                    q0 = lds_read4(a); q1 = lds_read4(a + q); q2 = lds_read4(a + 2u * q); q3 = lds_read4(a + 3u * q);
 #ifdef RT_FLOW_COUNT
                     ++c_lds;
 #endif
@@ -225,61 +269,81 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A,
                 if (tk >= count) blas_pop();                            // RK:324-329
             }
         } else if (run == 0u) {
-            // ---- TLAS: one step of RK:179-240 -- an inner node, or the next instance of a leaf ----
-            if (st == ST_TLAS) {
-                const uint32_t count = tnode >> 16, left = tnode & 0xFFFFu;
-                const v3 o = shadow ? sc.lightPos : ro, d = shadow ? sdir : rd;
-                bool pop = false;
-                if (count == 0u) {                                      // RK:183
-                    uint32_t i2 = left + 1u;
-                    const NodeR c1 = load_node_head(T, L, left), c2 = load_node_head(T, L, left + 1u);
-                    const v3 winv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    float d1 = hit_aabb(o, winv, c1);                   // RK:186
-                    float d2 = hit_aabb(o, winv, c2);                   // RK:187
-                    const bool swap = d1 > d2;                          // RK:190-196
-                    if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; i2 = left; }
-                    if (d1 > nearest) {                                 // RK:198
-                        pop = true;
+            // ---- TLAS: RK:179-240 up to and including the set-up of the next instance (RK:246-269).  Inner nodes, exhausted
+            // leaves and pops are a few instructions each and are walked through here, in a loop of the wave, until every lane
+            // of the block stands before an instance or has completed its ray: the expensive part -- the ray's transform and
+            // three divisions -- then runs once, for all of them.
+            const v3 o = shadow ? sc.lightPos : ro, d = shadow ? sdir : rd;
+            bool nav = st == ST_TLAS;
+            while (__ballot(nav) != 0ull) {
+                if (nav) {
+                    const uint32_t count = tnode >> 16, left = tnode & 0xFFFFu;
+                    bool pop = false;
+                    if (count == 0u) {                                  // RK:183
+                        uint32_t i2 = left + 1u;
+                        const NodeR c1 = flow_node(T, a_nodes, L.n_nodes, left), c2 = flow_node(T, a_nodes, L.n_nodes, left + 1u);
+                        const v3 winv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        float d1 = hit_aabb(o, winv, c1);               // RK:186
+                        float d2 = hit_aabb(o, winv, c2);               // RK:187
+                        const bool swap = d1 > d2;                      // RK:190-196
+                        if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; i2 = left; }
+                        if (d1 > nearest) {                             // RK:198
+                            pop = true;
+                        } else {
+                            tnode = pack_node(swap ? c2 : c1);          // RK:208
+                            ti = 0u;
+                            if (d2 < nearest) {                         // RK:209
+                                tpush(sclamp(sp_t), i2 < T.n_nodes ? i2 : T.n_nodes - 1u);
+                                sp_t += 1u;
+                                if (sp_t > kStack) sp_t = kStack - 1u;  // RK:212-214 guards with `>`
+                            }
+                        }
+                    } else if (ti < count) {
+                        nav = false;                                    // RK:220: instance ti of this leaf is next
                     } else {
-                        tnode = pack_node(swap ? c2 : c1);              // RK:208
-                        ti = 0u;
-                        if (d2 < nearest) {                             // RK:209
-                            tpush(sclamp(sp_t), i2 < T.n_nodes ? i2 : T.n_nodes - 1u);
-                            sp_t += 1u;
-                            if (sp_t > kStack) sp_t = kStack - 1u;      // RK:212-214 guards with `>`
+                        pop = true;                                     // RK:233
+                    }
+                    if (pop) {
+                        if (sp_t == 0u) {
+                            st = shadow ? ST_SDONE : ST_RDONE;          // the ray is complete
+                            nav = false;
+                        } else {
+                            sp_t -= 1u;
+                            tnode = pack_node(flow_node(T, a_nodes, L.n_nodes, tread(sclamp(sp_t))));   // RK:237-238
+                            ti = 0u;
                         }
                     }
-                } else if (ti < count) {                                // RK:220: instance ti of this leaf (RK:246-269)
-                    uint32_t li = ti + left;
-                    if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
-                    uint32_t bi = u32f(li < L.n_lookup ? s_blas[20u * li + 19u] : T.blas_lookup[li]);   // RK:223
-                    if (bi >= T.n_blas) bi = T.n_blas - 1u;
-                    const float* m = s_blas + 20u * bi;                 // mat4 column-major, m[4c + r]; every instance is staged (flow_ok)
-                    oo = V(((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.0f,
-                           ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.0f,
-                           ((m[2] * o.x + m[6] * o.y) + m[10] * o.z) + m[14] * 1.0f);       // RK:254
-                    od = V(((m[0] * d.x + m[4] * d.y) + m[8] * d.z) + m[12] * 0.0f,
-                           ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.0f,
-                           ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.0f);       // RK:255
-                    inv = V(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);     // RK:396
-                    bnode = __float_as_uint(m[17]);                     // RK:265: the root's (count, left), relinked
-                    cbi = bi;
-                    sp_b = 0u;                                          // RK:267
-                    bnear = nearest;                                    // RK:269
-                    tk = 0u;
-                    st = (bnode >> 16) == 0u ? ST_BNODE : ST_TRI;
-                } else {
-                    pop = true;                                         // RK:233
                 }
-                if (pop) {
-                    if (sp_t == 0u) {
-                        st = shadow ? ST_SDONE : ST_RDONE;              // the ray is complete
-                    } else {
-                        sp_t -= 1u;
-                        tnode = pack_node(load_node_head(T, L, tread(sclamp(sp_t))));   // RK:237-238
-                        ti = 0u;
-                    }
+            }
+            if (st == ST_TLAS) {
+                const uint32_t left = tnode & 0xFFFFu;
+                uint32_t li = ti + left;
+                if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
+                float bif;
+                if (li < L.n_lookup) bif = lds_read1(a_blas + 80u * li + 76u); else bif = T.blas_lookup[li];   // RK:223
+                uint32_t bi = u32f(bif);
+                if (bi >= T.n_blas) bi = T.n_blas - 1u;
+                float m[18];                                            // mat4 column-major, m[4c + r]; every instance is staged (flow_ok)
+                {
+                    const uint32_t a = a_blas + 80u * bi;
+                    const float4 r0 = lds_read4(a), r1 = lds_read4(a + 16u), r2 = lds_read4(a + 32u), r3 = lds_read4(a + 48u);
+                    m[0] = r0.x; m[1] = r0.y; m[2] = r0.z; m[3] = r0.w; m[4] = r1.x; m[5] = r1.y; m[6] = r1.z; m[7] = r1.w;
+                    m[8] = r2.x; m[9] = r2.y; m[10] = r2.z; m[11] = r2.w; m[12] = r3.x; m[13] = r3.y; m[14] = r3.z; m[15] = r3.w;
+                    m[17] = lds_read1(a + 68u);
                 }
+                oo = V(((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.0f,
+                       ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.0f,
+                       ((m[2] * o.x + m[6] * o.y) + m[10] * o.z) + m[14] * 1.0f);           // RK:254
+                od = V(((m[0] * d.x + m[4] * d.y) + m[8] * d.z) + m[12] * 0.0f,
+                       ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.0f,
+                       ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.0f);           // RK:255
+                inv = V(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);         // RK:396
+                bnode = __float_as_uint(m[17]);                         // RK:265: the root's (count, left), relinked
+                cbi = bi;
+                sp_b = 0u;                                              // RK:267
+                bnear = nearest;                                        // RK:269
+                tk = 0u;
+                st = (bnode >> 16) == 0u ? ST_BNODE : ST_TRI;
             }
         } else {
             // ---- DONE: complete rays are shaded (RK:114-141, RK:146-166), finished pixels stored, idle lanes refilled ----
