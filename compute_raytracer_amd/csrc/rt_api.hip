@@ -156,6 +156,7 @@ const char* rt_kernel_name(int id) {
         case RT_KID_TRIANGLES: return "trace_triangles";
         case RT_KID_HEATMAP: return "heatmap_triangles";
         case RT_KID_TRIANGLES_FLOW: return "trace_flow";
+        case RT_KID_TRIANGLES_TILES: return "trace_tiles";
         default: return "none";
     }
 }
@@ -693,7 +694,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     bool use_flow = false;
     RtFlowArgs fl;
     std::memset(&fl, 0, sizeof fl);
-    if (tri && c->kernel != RT_KERNEL_HEATMAP && c->variant != 6) {
+    if (tri && c->kernel != RT_KERNEL_HEATMAP && (c->variant == 7 || c->variant == 8)) {
         const uint32_t n_nodes = (uint32_t)(c->nodes_used / 32u);
         const uint32_t n_inst = (uint32_t)(c->inst.blas.size() / 20u);
         const bool fits = c->inst.blas_on && c->inst.lookup_on && n_inst >= 1u && n_inst <= kFlowInst && !c->inst.lookup.empty() &&
@@ -859,7 +860,8 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     const uint32_t order_n = ((c->W + 7u) / 8u) * fa.n_local_tiles;
     // ... and only for a caller that waits after each frame (the reference's loop): with frames in flight the tiles of
     // the next frame fill the slots a long tile leaves idle anyway, and row-major order keeps neighbours in one L2
-    if (tri && !use_flow && c->kernel != RT_KERNEL_HEATMAP && order_n >= kOrderMinTiles && !hint) {
+    const bool flow_steps = use_flow && c->variant == 7;     // the step machine takes pixels, not tiles: no order to choose
+    if (tri && !flow_steps && c->kernel != RT_KERNEL_HEATMAP && order_n >= kOrderMinTiles && !hint) {
         for (int k = 0; k < kStreams; ++k) if (s == c->streams[k]) order_set = k;
         if (order_set >= 0 && c->d_tile_cost[order_set].cap < (size_t)order_n * 4u) {
             // only frames on this stream use the set: wait for them, not for the batch (no slot bookkeeping involved)
@@ -909,6 +911,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             if (const char* e = getenv("RT355_FLOW_PERCU")) per_cu = (uint32_t)atoi(e);
             if (const char* e = getenv("RT355_FLOW_BLOCKS")) blocks = (uint32_t)atoi(e);
             if (const char* e = getenv("RT355_FLOW_THRESH")) fl.thresh = (uint32_t)atoi(e);
+            if (const char* e = getenv("RT355_FLOW_LDSPAIRS")) fl.lds_pairs_cap = (uint32_t)atoi(e) + 1u;
             if (waves != 16u && waves != 8u && waves != 4u) waves = 16u;
             if (per_cu < 1u) per_cu = 1u;
             if (blocks * waves > c->n_cus * 16u) blocks = c->n_cus * 16u / waves;      // the overflow area is sized for that many waves
@@ -918,7 +921,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             // one overflow area per frame that may be running: the frame kStreams slots back must be through with this one
             if (slot >= (uint32_t)kStreams) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[slot - (uint32_t)kStreams], 0));
             fl.ovf = static_cast<uint32_t*>(c->d_flow_ovf[slot % (uint32_t)kStreams].p);
-            RT_HIP(rt_launch_flow(fa, ts, fl, waves, per_cu, blocks, s));
+            RT_HIP(rt_launch_flow(fa, ts, fl, waves, per_cu, blocks, flow_steps, s));
         } else {
             RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
         }

@@ -448,6 +448,272 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A,
     count_rays(A.rays, nrays);
 }
 
+
+// =====================================================================================================================
+// trace_tiles -- the tile-per-wave form of rt_triangles.hip (a pixel per lane for the pixel's whole life, the reference's
+// nested walks as nested loops: neighbouring rays keep their lanes in step) on the memory layout of this file: persistent
+// 16-wave workgroups take tiles (or quarter tiles) from the frame's cursor, the BLAS walk reads the relinked pair records
+// -- LDS for the staged head, global memory below --, metas come packed, the stacks are the hybrid ones.  Measured against
+// trace_flow (profiles/r04): the step machine executes 1.5 x the vector instructions of the nested loops at 27 of 64 lanes
+// per block run; coherent waves are the cheaper way through this scene, and what the nested loops lacked was the short
+// latency of the upper tree levels and an end of the frame that is not one workgroup per tile.
+struct TileCtx {
+    uint32_t a_nodes, a_blas, a_pairs, a_bst, a_tst, n_head, n_lookup, lds_pairs, q;
+    uint32_t* ovf_b; uint16_t* ovf_t;
+    const float4* pairs;
+};
+
+template <int WAVES>
+__device__ __forceinline__ void tiles_bpush(const TileCtx& C, uint32_t s, uint32_t v) {
+    if (s < kFlowKB) *(lds_u32)(uintptr_t)(C.a_bst + s * (64u * WAVES * 4u)) = v;
+    else C.ovf_b[(s - kFlowKB) * 64u] = v;
+}
+template <int WAVES>
+__device__ __forceinline__ uint32_t tiles_bread(const TileCtx& C, uint32_t s) {
+    uint32_t v;
+    if (s < kFlowKB) v = *(lds_u32)(uintptr_t)(C.a_bst + s * (64u * WAVES * 4u));
+    else v = C.ovf_b[(s - kFlowKB) * 64u];
+    return v;
+}
+template <int WAVES>
+__device__ __forceinline__ void tiles_tpush(const TileCtx& C, uint32_t s, uint32_t v) {
+    if (s < kFlowKT) *(lds_u16)(uintptr_t)(C.a_tst + s * (64u * WAVES * 2u)) = (uint16_t)v;
+    else C.ovf_t[(s - kFlowKT) * 64u] = (uint16_t)v;
+}
+template <int WAVES>
+__device__ __forceinline__ uint32_t tiles_tread(const TileCtx& C, uint32_t s) {
+    uint32_t v;
+    if (s < kFlowKT) v = (uint32_t)*(lds_u16)(uintptr_t)(C.a_tst + s * (64u * WAVES * 2u));
+    else v = (uint32_t)C.ovf_t[(s - kFlowKT) * 64u];
+    return v;
+}
+
+// RK:246-332 traceBLAS over pair records (the normal transform RK:334-338 is deferred to hit_normal, as in rt_triangles.hip)
+template <int WAVES>
+__device__ __forceinline__ void tiles_blas(const RtTriScene& T, const TileCtx& C, uint32_t bi, v3 o, v3 d, float& nearest, TriHit& hit) {
+    float m[18];                                                    // mat4 column-major, m[4c + r]; m[17]: the root's meta
+    {
+        const uint32_t a = C.a_blas + 80u * bi;
+        const float4 r0 = lds_read4(a), r1 = lds_read4(a + 16u), r2 = lds_read4(a + 32u), r3 = lds_read4(a + 48u);
+        m[0] = r0.x; m[1] = r0.y; m[2] = r0.z; m[3] = r0.w; m[4] = r1.x; m[5] = r1.y; m[6] = r1.z; m[7] = r1.w;
+        m[8] = r2.x; m[9] = r2.y; m[10] = r2.z; m[11] = r2.w; m[12] = r3.x; m[13] = r3.y; m[14] = r3.z; m[15] = r3.w;
+        m[17] = lds_read1(a + 68u);
+    }
+    const v3 oo = V(((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.0f,
+                    ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.0f,
+                    ((m[2] * o.x + m[6] * o.y) + m[10] * o.z) + m[14] * 1.0f);       // RK:254
+    const v3 od = V(((m[0] * d.x + m[4] * d.y) + m[8] * d.z) + m[12] * 0.0f,
+                    ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.0f,
+                    ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.0f);       // RK:255
+    const v3 inv = V(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);        // RK:396
+    uint32_t node = __float_as_uint(m[17]);                         // RK:265
+    uint32_t sp = 0;                                                // RK:267
+    float blasNearest = nearest;                                    // RK:269
+    for (;;) {                                                      // RK:271
+        const uint32_t count = node >> 16, left = node & 0xFFFFu;   // RK:272-273
+        if (count == 0u) {                                          // RK:275
+            float4 q0, q1, q2, q3;
+            if (left < C.lds_pairs) {
+                const uint32_t a = C.a_pairs + 16u * left;
+                q0 = lds_read4(a); q1 = lds_read4(a + C.q); q2 = lds_read4(a + 2u * C.q); q3 = lds_read4(a + 3u * C.q);
+            } else {
+                const float4* g = C.pairs + 4u * (size_t)left;
+                q0 = g[0]; q1 = g[1]; q2 = g[2]; q3 = g[3];
+            }
+            NodeR c1, c2;
+            c1.lo = V(q0.x, q0.y, q0.z); c1.hi = V(q1.x, q1.y, q1.z);
+            c2.lo = V(q2.x, q2.y, q2.z); c2.hi = V(q3.x, q3.y, q3.z);
+            const uint32_t m1 = __float_as_uint(q0.w), m2 = __float_as_uint(q2.w);
+            float d1 = hit_aabb(oo, inv, c1);                       // RK:279
+            float d2 = hit_aabb(oo, inv, c2);                       // RK:280
+            const bool swap = d1 > d2;                              // RK:283-290
+            if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; }
+            if (d1 > blasNearest) {                                 // RK:292
+                if (sp == 0u) break;
+                sp -= 1u;
+                node = tiles_bread<WAVES>(C, sclamp(sp));           // RK:297-298
+            } else {
+                node = swap ? m2 : m1;                              // RK:302
+                if (d2 < blasNearest) {                             // RK:303-304 (no overflow guard upstream)
+                    tiles_bpush<WAVES>(C, sclamp(sp), swap ? m1 : m2);
+                    sp += 1u;
+                }
+            }
+        } else {
+            for (uint32_t i = 0; i < count; ++i) {                  // RK:311
+                uint32_t li = i + left;
+                if (li >= T.n_tri_lookup) li = T.n_tri_lookup - 1u;  // RK:314: the lookup itself is folded into T.corners
+                float t, u, v;
+                if (hit_triangle(T, li, oo, od, blasNearest, t, u, v)) {   // RK:312-321
+                    blasNearest = t;
+                    hit.t = t; hit.u = u; hit.v = v; hit.tri = (int)li; hit.blas = (int)bi;
+                }
+            }
+            if (sp == 0u) break;                                    // RK:324
+            sp -= 1u;
+            node = tiles_bread<WAVES>(C, sclamp(sp));               // RK:328-329
+        }
+    }
+    nearest = blasNearest < nearest ? blasNearest : nearest;        // RK:227-229
+}
+
+// RK:168-244 traceTLAS
+template <int WAVES>
+__device__ __forceinline__ TriHit tiles_tlas(const RtTriScene& T, const TileCtx& C, v3 o, v3 d) {
+    TriHit hit; hit.t = 0.0f; hit.u = hit.v = 0.0f; hit.tri = -1; hit.blas = -1;   // RK:170-171
+    float nearest = 9999.0f;                                        // RK:172
+    const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    NodeR node = flow_node(T, C.a_nodes, C.n_head, 0u);             // RK:175
+    uint32_t sp = 0;
+    for (;;) {                                                      // RK:179
+        const uint32_t count = u32f(node.count);                    // RK:180
+        const uint32_t left = u32f(node.left);                      // RK:181
+        if (count == 0u) {                                          // RK:183
+            uint32_t i2 = left + 1u;
+            const NodeR c1 = flow_node(T, C.a_nodes, C.n_head, left), c2 = flow_node(T, C.a_nodes, C.n_head, left + 1u);
+            float d1 = hit_aabb(o, inv, c1);                        // RK:186
+            float d2 = hit_aabb(o, inv, c2);                        // RK:187
+            const bool swap = d1 > d2;                              // RK:190-196
+            if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; i2 = left; }
+            if (d1 > nearest) {                                     // RK:198
+                if (sp == 0u) break;
+                sp -= 1u;
+                node = flow_node(T, C.a_nodes, C.n_head, tiles_tread<WAVES>(C, sclamp(sp)));
+            } else {
+                node = swap ? c2 : c1;                              // RK:208
+                if (d2 < nearest) {                                 // RK:209
+                    tiles_tpush<WAVES>(C, sclamp(sp), i2 < T.n_nodes ? i2 : T.n_nodes - 1u);
+                    sp += 1u;
+                    if (sp > kStack) sp = kStack - 1u;              // RK:212-214 guards with `>`
+                }
+            }
+        } else {
+            for (uint32_t i = 0; i < count; ++i) {                  // RK:220
+                uint32_t li = i + left;
+                if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
+                float bif;
+                if (li < C.n_lookup) bif = lds_read1(C.a_blas + 80u * li + 76u); else bif = T.blas_lookup[li];   // RK:223
+                uint32_t bi = u32f(bif);
+                if (bi >= T.n_blas) bi = T.n_blas - 1u;
+                tiles_blas<WAVES>(T, C, bi, o, d, nearest, hit);    // RK:221-230
+            }
+            if (sp == 0u) break;                                    // RK:233
+            sp -= 1u;
+            node = flow_node(T, C.a_nodes, C.n_head, tiles_tread<WAVES>(C, sclamp(sp)));   // RK:237-238
+        }
+    }
+    return hit;
+}
+
+template <int WAVES, bool FLAT>
+__global__ __launch_bounds__(64 * WAVES, 4) void trace_tiles(const RtFrameArgs A, const RtTriScene T, const RtFlowArgs F) {
+    extern __shared__ float4 lds[];
+    constexpr uint32_t stride = 64u * WAVES;
+    float4* const s_nodes = lds;
+    float* const s_blas = reinterpret_cast<float*>(lds + 2u * kLdsNodes);
+    uint32_t* const s_bstack = reinterpret_cast<uint32_t*>(s_blas + 20u * kFlowInst);
+    uint16_t* const s_tstack = reinterpret_cast<uint16_t*>(s_bstack + kFlowKB * stride);
+    float4* const s_pairs = reinterpret_cast<float4*>(s_tstack + kFlowKT * stride);
+    const uint32_t n_head = T.n_nodes < kLdsNodes ? T.n_nodes : kLdsNodes;
+    const uint32_t n_blas = T.n_blas < kFlowInst ? T.n_blas : kFlowInst;
+    const uint32_t n_lookup = T.n_blas_lookup < n_blas ? T.n_blas_lookup : n_blas;
+    for (uint32_t i = threadIdx.x; i < 2u * n_head; i += stride) s_nodes[i] = T.nodes[i];
+    for (uint32_t i = threadIdx.x; i < 20u * n_blas; i += stride) {
+        const uint32_t r = i / 20u, k = i % 20u;
+        float v = T.blas[i];
+        if (k == 17u) v = __uint_as_float(F.root_meta[r]);
+        if (k == 19u && r < n_lookup) v = T.blas_lookup[r];
+        s_blas[i] = v;
+    }
+    for (uint32_t i = threadIdx.x; i < 4u * F.lds_pairs; i += stride) s_pairs[(i & 3u) * F.lds_pairs + (i >> 2)] = F.pairs[i];   // quarter-major, see trace_flow
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    TileCtx C;
+    C.a_nodes = (uint32_t)(uintptr_t)s_nodes; C.a_blas = (uint32_t)(uintptr_t)s_blas; C.a_pairs = (uint32_t)(uintptr_t)s_pairs;
+    C.a_bst = (uint32_t)(uintptr_t)(s_bstack + threadIdx.x); C.a_tst = (uint32_t)(uintptr_t)(s_tstack + threadIdx.x);
+    C.n_head = n_head; C.n_lookup = n_lookup; C.lds_pairs = F.lds_pairs; C.q = 16u * F.lds_pairs;
+    C.ovf_b = F.ovf + (size_t)(blockIdx.x * WAVES + wave) * kFlowOvfWords + lane;
+    C.ovf_t = reinterpret_cast<uint16_t*>(F.ovf + (size_t)(blockIdx.x * WAVES + wave) * kFlowOvfWords + (kStack - kFlowKB) * 64u) + lane;
+    C.pairs = F.pairs;
+
+    const Scene sc = unpack_scene(A);
+    const uint32_t groups_x = (A.W + 7u) / 8u;
+    const uint32_t n_tiles = groups_x * A.n_local_tiles;
+    const uint32_t split = T.tile_order ? T.tile_order[0] : 0u;
+    const uint32_t n_items = n_tiles + 3u * split;                  // a split tile is four items, one 4x4 quarter each
+    uint32_t nrays = 0;
+    // Items come from the frame's cursor in chunks: every wave starts with the item of its own number (no atomic), then
+    // reserves remaining / (4 x waves of the grid) items at a time, at least one, at most sixteen -- atomics on ONE address
+    // complete about 12 ns apart, and a 4K frame has 129,600 tiles: one atomic per tile would be a 1.6 ms floor under the frame.
+    const uint32_t grid_waves = gridDim.x * (uint32_t)WAVES;
+    uint32_t item = blockIdx.x * (uint32_t)WAVES + wave, item_end = item + 1u;
+    for (;; ++item) {
+        if (item == item_end) {
+            const uint32_t seen = item < grid_waves ? grid_waves : item;          // a lower bound of the cursor
+            uint32_t want = n_items > seen ? (n_items - seen) / (4u * grid_waves) : 0u;
+            want = want < 1u ? 1u : (want > 16u ? 16u : want);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.qctrl[2], want);
+            base = __builtin_amdgcn_readfirstlane(base) + grid_waves;
+            item = base; item_end = base + want;
+        }
+        if (item >= n_items) break;
+        const uint64_t clk0 = wall_clock64();
+        uint32_t tile = item, part = 4u;                            // part 0-3: a 4x4 quarter; 4: the whole tile
+        if (T.tile_order) {
+            if (item < 4u * split) { tile = T.tile_order[1u + (item >> 2)]; part = item & 3u; }
+            else tile = T.tile_order[1u + item - 3u * split];
+        }
+        const uint32_t by = tile / groups_x, bx = tile - by * groups_x;
+        const uint32_t px = part == 4u ? (lane & 7u) : 4u * (part & 1u) + (lane & 3u);
+        const uint32_t row = part == 4u ? (lane >> 3) : 4u * (part >> 1) + (lane >> 2);
+        const uint32_t x = bx * 8u + px;
+        const uint32_t y = (A.tile_first + by * A.tile_step) * 8u + row;
+        if ((part == 4u || lane < 16u) && x < A.W && y < A.H) {
+            float dist = 0.0f;
+            v3 color = V(1.0f, 1.0f, 1.0f);
+            v3 ro = sc.cameraPos, rd = primary_dir(A, sc, x, y);
+            float affect = 1.0f, sum = 0.0f;
+            for (uint32_t bounce = 0; bounce < sc.bounces; ++bounce) {                       // RK:113
+                const TriHit h = tiles_tlas<WAVES>(T, C, ro, rd);                            // RK:114
+                ++nrays;
+                const bool hit = h.tri >= 0;
+                if (bounce == 0) dist = hit ? h.t : 0.0f;                                    // RK:116-118
+                const float next = affect + sum;                                             // RK:120
+                if (!hit) {                                                                  // RK:122-126
+                    const v3 sky = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, rd));
+                    color = divs(add(scale(sum, color), scale(affect, sky)), next);
+                    break;
+                }
+                const v3 normal = hit_normal(T, h);
+                const int tri = h.tri;
+                const float hu = h.u, hv = h.v;
+                ro = add(ro, scale(h.t, rd));                                                // RK:129
+                rd = normalize(reflect(rd, normal));                                         // RK:130
+                // RK:146-166
+                const v3 sdir = normalize(sub(ro, sc.lightPos));
+                const float distance = length(sdir);
+                const TriHit sh = tiles_tlas<WAVES>(T, C, sc.lightPos, sdir);                // RK:153
+                ++nrays;
+                const float intensity = light_term(sc, ro, normal, sdir, distance, sh.tri >= 0, sh.t);
+                const Albedo s = hit_albedo(T, tri, hu, hv);
+                const v3 diffuseColor = scale(s.w, s.rgb);                                   // RK:133
+                const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));        // RK:134
+                const v3 blended = scale(intensity, add(diffuseColor, samplerColor));        // RK:135
+                color = divs(add(scale(sum, color), scale(affect, blended)), next);          // RK:136
+                affect = affect / 2.0f;                                                      // RK:139
+                sum = next;                                                                  // RK:140
+            }
+            const uint32_t opix = (by * 8u + row) * A.W + x;
+            reinterpret_cast<uint32_t*>(A.out)[opix] =
+                compose_pixel_sky(scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, primary_dir(A, sc, x, y))), color, dist);   // RK:91-98
+        }
+        if (T.tile_cost && lane == 0u) atomicAdd(&T.tile_cost[tile], (uint32_t)(wall_clock64() - clk0));   // 10 ns ticks; quarters add up
+    }
+    count_rays(A.rays, nrays);
+}
+
 }  // namespace rtk
 
 #ifdef RT_FLOW_COUNT
@@ -477,6 +743,20 @@ uint32_t rt_flow_lds_pairs(uint32_t waves, uint32_t per_cu, uint32_t n_pairs) {
 }
 
 template <int WAVES>
+static hipError_t launch_tiles_as(const RtFrameArgs& a, const RtTriScene& t, RtFlowArgs f, uint32_t per_cu, uint32_t blocks, hipStream_t s) {
+    f.lds_pairs = rt_flow_lds_pairs(WAVES, per_cu, f.n_pairs);
+    if (f.lds_pairs_cap && f.lds_pairs > f.lds_pairs_cap - 1u) f.lds_pairs = f.lds_pairs_cap - 1u;
+    const size_t lds = rt_flow_lds_bytes(WAVES, f.lds_pairs);
+    auto k = a.sky_flat ? rtk::trace_tiles<WAVES, true> : rtk::trace_tiles<WAVES, false>;
+    if (lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a, t, f);
+    return hipGetLastError();
+}
+
+template <int WAVES>
 static hipError_t launch_flow_as(const RtFrameArgs& a, const RtTriScene& t, RtFlowArgs f, uint32_t per_cu, uint32_t blocks, hipStream_t s) {
     f.lds_pairs = rt_flow_lds_pairs(WAVES, per_cu, f.n_pairs);
     const size_t lds = rt_flow_lds_bytes(WAVES, f.lds_pairs);
@@ -492,8 +772,15 @@ static hipError_t launch_flow_as(const RtFrameArgs& a, const RtTriScene& t, RtFl
 }
 
 // waves: waves per workgroup (16 / 8 / 4); per_cu: workgroups of this frame's launch sized to share a CU.
-hipError_t rt_launch_flow(const RtFrameArgs& a, const RtTriScene& t, const RtFlowArgs& f, uint32_t waves, uint32_t per_cu, uint32_t blocks, hipStream_t s) {
+// steps: the step machine (trace_flow) instead of the tile-per-wave form (trace_tiles).
+hipError_t rt_launch_flow(const RtFrameArgs& a, const RtTriScene& t, const RtFlowArgs& f, uint32_t waves, uint32_t per_cu, uint32_t blocks, bool steps, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    if (!steps) {
+        g_rt_kernel_id = RT_KID_TRIANGLES_TILES;
+        if (waves == 16u) return launch_tiles_as<16>(a, t, f, per_cu, blocks, s);
+        if (waves == 8u) return launch_tiles_as<8>(a, t, f, per_cu, blocks, s);
+        return launch_tiles_as<4>(a, t, f, per_cu, blocks, s);
+    }
     g_rt_kernel_id = RT_KID_TRIANGLES_FLOW;
     if (waves == 16u) return launch_flow_as<16>(a, t, f, per_cu, blocks, s);
     if (waves == 8u) return launch_flow_as<8>(a, t, f, per_cu, blocks, s);

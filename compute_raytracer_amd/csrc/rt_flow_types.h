@@ -14,8 +14,9 @@ struct RtFlowArgs {
     uint32_t thresh;                    // complete rays a wave collects before it runs the shading block
     uint32_t root_meta[kFlowInst];      // per instance: (count << 16 | left) of its root node, inner roots relinked
     uint32_t* ovf;                      // overflow stacks: kFlowOvfWords words per wave of the grid
+    uint32_t lds_pairs_cap;             // development knob: at most this many staged records (0: no limit)
 };
 
 size_t rt_flow_lds_bytes(uint32_t waves, uint32_t lds_pairs);
 uint32_t rt_flow_lds_pairs(uint32_t waves, uint32_t per_cu, uint32_t n_pairs);
-hipError_t rt_launch_flow(const RtFrameArgs& a, const RtTriScene& t, const RtFlowArgs& f, uint32_t waves, uint32_t per_cu, uint32_t blocks, hipStream_t s);
+hipError_t rt_launch_flow(const RtFrameArgs& a, const RtTriScene& t, const RtFlowArgs& f, uint32_t waves, uint32_t per_cu, uint32_t blocks, bool steps, hipStream_t s);

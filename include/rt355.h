@@ -65,7 +65,8 @@ typedef enum rt_kernel_id {
     RT_KID_HIERARCHY_GLOBAL = 7, /* nodes read from global memory (scenes beyond a CU's LDS) */
     RT_KID_TRIANGLES = 8,        /* trace_triangles (TLAS / BLAS traversal) */
     RT_KID_HEATMAP = 9,          /* heatmap_triangles */
-    RT_KID_TRIANGLES_FLOW = 10   /* trace_flow: persistent waves, one traversal step per trip, BLAS heads in LDS (rt_flow.hip) */
+    RT_KID_TRIANGLES_FLOW = 10,  /* trace_flow: persistent waves, one traversal step per trip, BLAS heads in LDS (rt_flow.hip) */
+    RT_KID_TRIANGLES_TILES = 11  /* trace_tiles: persistent waves, a tile per wave at a time, BLAS heads in LDS (rt_flow.hip) */
 } rt_kernel_id;
 
 typedef enum rt_kernel {
@@ -180,9 +181,10 @@ int rt_set_mode(rt_ctx* ctx, int mode);
  * 0 = bounding-sphere hierarchy from 128 spheres on (from 72 on once the caller keeps frames in flight), single
  * brute-force kernel below;
  * 4 = hierarchy for any sphere count; 5 = brute force (two-kernel pipeline from 320 spheres on);
- * 1, 2, 3 = individual brute-force forms.  Triangle scenes: 0 = the persistent kernel (rt_flow.hip) for scenes of up to
- * 16 instances whose node buffer and lookup table fit 16-bit indices, the tile-per-wave kernel (rt_triangles.hip) otherwise;
- * 6 = the tile-per-wave kernel always.  Every variant produces the same pixels.  See DESIGN.md. */
+ * 1, 2, 3 = individual brute-force forms.  Triangle scenes: 0 (and 6) = one workgroup per tile (rt_triangles.hip);
+ * 7 / 8 = the persistent kernels of rt_flow.hip -- the step machine trace_flow / the tile loop trace_tiles -- for scenes of up
+ * to 16 instances whose node buffer and lookup table fit 16-bit indices (others fall back to 0): measured slower than the
+ * default, kept selectable.  Every variant produces the same pixels.  See DESIGN.md. */
 int rt_set_variant(rt_ctx* ctx, int variant);
 
 /* ---- multi-GPU partition --------------------------------------------------------------- */

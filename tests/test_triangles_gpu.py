@@ -22,12 +22,12 @@ def random_sky(seed, w=8, h=8):
     return m
 
 
-# both kernels of the triangle path: 0 = the library's choice (the persistent kernel, rt_flow.hip: these scenes fit it),
-# 6 = the tile-per-wave kernel (rt_triangles.hip)
-KERNELS = {0: "triangles_flow", 6: "triangles"}
+# the kernels of the triangle path: 0 = the library's choice, one workgroup per tile (rt_triangles.hip); 7 = the step machine,
+# 8 = the persistent tile loop (rt_flow.hip: trace_flow / trace_tiles; these scenes fit them)
+KERNELS = {0: "triangles", 7: "triangles_flow", 8: "triangles_tiles"}
 
 
-@pytest.mark.parametrize("variant", [0, 6])
+@pytest.mark.parametrize("variant", [0, 7, 8])
 @pytest.mark.parametrize("seed,W,H,B", [(1, 320, 200, 4), (2, 333, 207, 2), (3, 64, 64, 8), (4, 8, 8, 1), (5, 200, 120, 0)])
 def test_triangle_scene_bit_exact(oracle, seed, W, H, B, variant):
     scene, mat = triangle_scene(seed=seed, n_models=3)
@@ -38,7 +38,7 @@ def test_triangle_scene_bit_exact(oracle, seed, W, H, B, variant):
     assert st["rays"] == rays and abi.KERNEL_IDS[st["kernel_id"]] == KERNELS[variant]
 
 
-@pytest.mark.parametrize("variant", [0, 6])
+@pytest.mark.parametrize("variant", [0, 7, 8])
 def test_finer_meshes_deeper_trees(oracle, variant):
     scene, mat = triangle_scene(seed=7, n_models=5, rings=24, sectors=32)
     assert scene.triangleCount > 3000
@@ -49,7 +49,7 @@ def test_finer_meshes_deeper_trees(oracle, variant):
     assert st["rays"] == rays and abi.KERNEL_IDS[st["kernel_id"]] == KERNELS[variant]
 
 
-@pytest.mark.parametrize("variant", [0, 6])
+@pytest.mark.parametrize("variant", [0, 7, 8])
 def test_animation_loop_rebuilds_tlas_each_frame(oracle, variant):
     """src/app.ts:117-128: scene.update(dt) (models spin, TLAS + BLAS matrices rebuilt, SR:138-143),
     camera.move, renderer.render: per frame only params, BLAS records, BLAS lookup and TLAS nodes
@@ -196,9 +196,9 @@ def test_large_instance_sets_and_whole_buffer_node_writes(oracle):
         r.close()
 
 
-@pytest.mark.parametrize("variant", [0, 6])
+@pytest.mark.parametrize("variant", [0, 7, 8])
 def test_tile_order_does_not_change_the_picture(oracle, variant):
-    """(variant 0: the same frames through the persistent kernel, whose lanes take pixels from a cursor.)
+    """(variants 7 / 8: the same frames through the persistent kernels, whose lanes / waves take pixels / tiles from a cursor.)
     From 4096 tiles on the triangle kernel starts a frame's tiles longest-first, in the order the previous frame on the
     same stream suggests (rt_triangles.hip: order_tiles).  1024 x 516 = 8320 tiles, ragged last row; the camera walks and
     the models spin, so every frame is rendered in an order made for another picture: ten frames one at a time (each of
@@ -290,7 +290,7 @@ def spine_scene(depth):
     return rt.SceneRaytracing.from_packed(d)
 
 
-@pytest.mark.parametrize("variant", [0, 6])
+@pytest.mark.parametrize("variant", [0, 7, 8])
 @pytest.mark.parametrize("depth", [7, 12, 19, 20, 21, 33])
 def test_stack_depth_beyond_the_lds_slots_and_beyond_the_reference_stack(oracle, depth, variant):
     scene = spine_scene(depth)

@@ -13,9 +13,9 @@ from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
 
 args = sys.argv[1:]
 configs = [a for a in args if a in ("REF", "TRI", "TRI4K")] or ["REF", "TRI", "TRI4K"]
-variants = [int(a[1:]) for a in args if a in ("v0", "v6")] or [0, 6]
+variants = [int(a[1:]) for a in args if a in ("v0", "v6", "v7", "v8")] or [0, 6]
 label = " ".join("%s=%s" % (k[6:], v) for k, v in sorted(os.environ.items()) if k.startswith("RT355_FLOW")) + " " + \
-        " ".join(a for a in args if a not in ("REF", "TRI", "TRI4K", "v0", "v6"))
+        " ".join(a for a in args if a not in ("REF", "TRI", "TRI4K", "v0", "v6", "v7"))
 _tri = None
 for name in configs:
     if name == "REF":
