@@ -35,7 +35,7 @@ $(CSRC)/rt_api.o: $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -DRT355_BUILD_ID='"$(BUILD_ID)"' -c $(CSRC)/rt_api.hip -o $@
 
 # the RCCL entry points (rt_comm_init / rt_render_gather / rt_group_*)
-$(CSRC)/rt_comm.o: $(CSRC)/rt_comm.hip $(CSRC)/rt_ctx.h $(CSRC)/rt_flow_types.h $(CSRC)/rt_flow_build.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h $(CSRC)/rt_wait_poll.h include/rt355.h
+$(CSRC)/rt_comm.o: $(CSRC)/rt_comm.hip $(CSRC)/rt_ctx.h $(CSRC)/rt_flow_types.h $(CSRC)/rt_flow_build.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h $(CSRC)/rt_wait_poll.h $(CSRC)/rt_exchange_plan.h include/rt355.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

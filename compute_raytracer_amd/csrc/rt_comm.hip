@@ -25,6 +25,9 @@
 #include <thread>
 
 #include "rt_wait_poll.h"
+#include "rt_exchange_plan.h"
+
+static_assert(kExchangeStreams == (uint32_t)kStreams, "rt_exchange_plan.h and rt_ctx.h must agree on the number of streams");
 
 struct rt_comm_state {
     ncclComm_t comm = nullptr;
@@ -57,7 +60,7 @@ static int fail_nccl(ncclResult_t r, const char* where) {
         if (r_ != ncclSuccess) return fail_nccl(r_, #call);            \
     } while (0)
 
-static size_t message_bytes(const rt_ctx* c) { return (size_t)rt_padded_tiles(c->H, c->world) * 8u * c->W * 4u; }
+static size_t message_bytes(const rt_ctx* c) { return rt_plan_message_bytes(c->W, c->H, c->world); }
 
 static void free_buffers(rt_ctx* c) {
     rt_comm_state* s = c->comm;
@@ -201,10 +204,9 @@ static int ensure_buffers(rt_ctx* c, bool receives) {
 // rt_group: one group over all its devices, as a single thread driving several GPUs must).
 static int render_part(rt_ctx* c, int root, uint32_t k, uint8_t** part) {
     rt_comm_state* s = c->comm;
-    const bool receives = root < 0 || (uint32_t)root == c->rank;
-    { int rc = ensure_buffers(c, receives); if (rc != RT_OK) return rc; }
-    const size_t msg = message_bytes(c);
-    *part = receives ? s->d_gather[k] + msg * c->rank : c->d_outs[k];
+    const RtXPlan plan = rt_exchange_plan(c->W, c->H, c->rank, c->world, root);
+    { int rc = ensure_buffers(c, plan.receives); if (rc != RT_OK) return rc; }
+    *part = plan.part_in_gather ? s->d_gather[k] + plan.part_offset : c->d_outs[k];
     if (!*part) return fail(RT_ERR_STATE, "rt_render_gather: rt_resize has not been called");
     int rc = rt_enqueue(c, *part, c->streams[k]);
     if (rc != RT_OK) return rc;
@@ -219,22 +221,23 @@ static int render_part(rt_ctx* c, int root, uint32_t k, uint8_t** part) {
 // frame waits for the exchange of the frame enqueued before it (not for its de-interleave, and the renders
 // stay free to overlap) -- instead of being left to how RCCL treats one communicator on several streams.
 static int order_exchange(rt_ctx* c, uint32_t k) {
-    const uint32_t slot = c->in_flight - 1u;
-    if (slot > 0u) RT_HIP(hipStreamWaitEvent(c->streams[k], c->comm->ev_x1[slot - 1u], 0));
+    const int before = rt_exchange_waits_on(c->in_flight - 1u);
+    if (before >= 0) RT_HIP(hipStreamWaitEvent(c->streams[k], c->comm->ev_x1[before], 0));
     return RT_OK;
 }
 
+// the frame's RCCL operations, as rt_exchange_plan.h lists them for this rank
 static int exchange_part(rt_ctx* c, int root, uint32_t k, uint8_t* part) {
     rt_comm_state* s = c->comm;
-    const size_t msg = message_bytes(c);
     hipStream_t st = c->streams[k];
-    if (root < 0) {
-        RT_NCCL(ncclAllGather(part, s->d_gather[k], msg, ncclUint8, s->comm, st));     // in place: part = recv + rank * msg
-    } else if ((uint32_t)root == c->rank) {
-        for (uint32_t r = 0; r < c->world; ++r)
-            if (r != c->rank) RT_NCCL(ncclRecv(s->d_gather[k] + msg * r, msg, ncclUint8, (int)r, s->comm, st));
-    } else {
-        RT_NCCL(ncclSend(part, msg, ncclUint8, root, s->comm, st));
+    const RtXPlan plan = rt_exchange_plan(c->W, c->H, c->rank, c->world, root);
+    for (const RtXOp& op : plan.ops) {
+        if (op.kind == RtXKind::AllGather)
+            RT_NCCL(ncclAllGather(s->d_gather[k] + op.gather_offset, s->d_gather[k], op.bytes, ncclUint8, s->comm, st));   // in place: part = recv + rank * msg
+        else if (op.kind == RtXKind::Recv)
+            RT_NCCL(ncclRecv(s->d_gather[k] + op.gather_offset, op.bytes, ncclUint8, (int)op.peer, s->comm, st));
+        else
+            RT_NCCL(ncclSend(part, op.bytes, ncclUint8, (int)op.peer, s->comm, st));
     }
     return RT_OK;
 }
@@ -325,7 +328,7 @@ static int poison(rt_ctx* c, int rc) {
 int rt_render_gather(rt_ctx* c, int root) {
     { int rc = prepare_gather(c, root, "rt_render_gather: ctx is NULL"); if (rc != RT_OK) return rc; }
     if (!c->comm->owns_comm) return fail(RT_ERR_STATE, "rt_render_gather: this context belongs to an rt_group; call rt_group_render");
-    const uint32_t k = c->frames_rendered % (uint32_t)kStreams;
+    const uint32_t k = rt_exchange_set(c->frames_rendered);
     uint8_t* part = nullptr;
     {
         const uint32_t before = c->in_flight;          // a render that failed before it enqueued anything leaves the group intact
@@ -434,7 +437,7 @@ int rt_group_render(rt_group* g, int root) {
     for (size_t d = 0; d < n; ++d) {
         rt_ctx* c = g->ctx[d];
         { hipError_t e = hipSetDevice(c->device); if (e != hipSuccess) return poison_all(fail_hip(e, "hipSetDevice")); }
-        k[d] = c->frames_rendered % (uint32_t)kStreams;
+        k[d] = rt_exchange_set(c->frames_rendered);
         {
             const uint32_t before = c->in_flight;
             int rc = render_part(c, root, k[d], &part[d]);

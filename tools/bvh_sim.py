@@ -117,18 +117,22 @@ def build_collapsed(split, bound, arity=4):
     return rec, link
 
 
+GROUP = False      # leaves of up to `leafmax` spheres under ONE bound, members appended untested (round 4 study)
 def build(split, bound, leafmax=4, arity=4):
     rec = []; link = []
     def leaf(i):
         rec.append((C[i], R[i])); link.append(("l", i))
     def emit(ids):
         if len(ids) == 1: leaf(ids[0]); return
+        if GROUP and len(ids) <= leafmax:
+            bc, br = bound(ids)
+            rec.append((bc, br * SIGMA)); link.append(("g", ids)); return
         me = len(rec); rec.append(None); link.append(None)
         children(ids)
         bc, br = bound(ids)
         rec[me] = (bc, br * SIGMA); link[me] = ("n", len(rec))
     def children(ids):
-        if len(ids) <= leafmax:
+        if len(ids) <= leafmax and not GROUP:
             for i in ids: leaf(i)
             return
         parts = [ids]
@@ -162,7 +166,17 @@ def traverse(rec, link, o, d):
         if TCULL and ok and cc > 0 and best < 1e29:
             ok = (-b - math.sqrt(b * b - cc)) < best        # entry distance beyond the nearest hit so far
         tests += 1
-        if kind == "l":
+        if kind == "g":
+            if ok:
+                for s_ in x:
+                    cands += 1
+                    oc2 = o - C[s_]; b2 = oc2 @ d; c2 = oc2 @ oc2 - R[s_] * R[s_]
+                    disc = b2 * b2 - c2
+                    if disc > 0 and b2 < 0:
+                        t = -b2 - math.sqrt(disc)
+                        if t > 1e-3 and t < best: best, bi = t, s_
+            i += 1
+        elif kind == "l":
             if ok:
                 cands += 1
                 disc = b * b - cc
@@ -225,8 +239,13 @@ for (name, split, bound, leafmax, arity), tc in itertools.product([
         ("collapse4 sahdiag", split_sah_diag, bound_ritter, 0, 4),
         ("collapse3 sahdiag", split_sah_diag, bound_ritter, 0, 3),
         ("collapse6 sahdiag", split_sah_diag, bound_ritter, 0, 6),
-        ("collapse2 sahdiag", split_sah_diag, bound_ritter, 0, 2)][5:], [False]):
+        ("collapse2 sahdiag", split_sah_diag, bound_ritter, 0, 2),
+        ("GROUP sahdiag/ritt 2/4", split_sah_diag, bound_ritter, 2, 4),
+        ("GROUP sahdiag/ritt 3/4", split_sah_diag, bound_ritter, 3, 4),
+        ("GROUP sahdiag/ritt 4/4", split_sah_diag, bound_ritter, 4, 4)][5:], [False]):
+    if os.environ.get('ONLY') and os.environ['ONLY'] not in name: continue
     TCULL = tc
+    GROUP = name.startswith('GROUP')
     rec, link = build(split, bound, leafmax, arity) if leafmax else build_collapsed(split, bound, arity)
     tests = np.array([traverse(rec, link, o, d)[2] for (_, o, d) in rays])
     cands = np.array([traverse(rec, link, o, d)[3] for (_, o, d) in rays[::7]])
