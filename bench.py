@@ -333,7 +333,7 @@ def main():
     # what a host that READS every frame gets (render, wait, copy the frame to pageable host memory: the PCIe-inclusive
     # rate -- never `value`), and, for a triangle scene, what the reference's animation loop costs (scene.update on the
     # host, the per-frame writes of RR:169-192, render, wait: src/app.ts:117-128)
-    readback_ms = streamed_ms = animated_ms = animated_host_ms = None
+    readback_ms = streamed_ms = animated_ms = animated_host_ms = loop_ms = None
     if not multi and ssteps > 0:
         r.enqueue(); r.wait(); r.read_pixels()
         t0 = time.perf_counter()
@@ -357,6 +357,32 @@ def main():
             return (time.perf_counter() - t0) / n * 1e3
         streamed(8)
         streamed_ms = streamed(max(ssteps, 24))
+        # The loop a drop-in runs (src/app.ts:117-128, RR:435-469), one frame at a time: scene.update / camera.move on the host,
+        # recalculateScene (rt_write_params; for a triangle scene also the three per-frame instance writes), rt_render, rt_wait.
+        # The Python scene layer's own update (numpy: matrices, inverses, the top-level rebuild) is kept out of it -- the K
+        # states are prepared beforehand, the loop installs one per step -- and reported by itself below (animated_host_scene_update_ms;
+        # animated_ms_per_step is the loop WITH it).
+        if tri:
+            pose = scene.instances.eulers.copy()
+            states = []
+            for _ in range(ssteps):
+                scene.update(0.016)
+                states.append(scene.frame)
+            r.render()
+            t0 = time.perf_counter()
+            for st_ in states:
+                scene.frame = st_
+                r.render()                                # recalculateScene + rt_render + rt_wait
+            loop_ms = (time.perf_counter() - t0) / ssteps * 1e3
+            scene.instances.eulers = pose
+            scene.buildTopLevel()
+        else:
+            r.render()
+            t0 = time.perf_counter()
+            for _ in range(ssteps):
+                scene.camera.move(0.0, 0.0)               # no key pressed: the picture stays the timed one
+                r.render()
+            loop_ms = (time.perf_counter() - t0) / ssteps * 1e3
         if tri:
             pose = scene.instances.eulers.copy()
             t0 = time.perf_counter()
@@ -520,6 +546,7 @@ def main():
             # copies every frame out pays the PCIe read-back; `value` / ms_per_step are frames enqueued back to back
             "serial_ms_per_step": serial_ms,
             "serial_value": (rays_frame / (serial_ms * 1e-3) / 1e6) if serial_ms else None,
+            "loop_ms_per_step": loop_ms,          # the reference's own loop through this library, one frame at a time (see above)
             "readback_ms_per_step": readback_ms,
             "streamed_readback_ms_per_step": streamed_ms,
             "animated_ms_per_step": animated_ms,
@@ -550,6 +577,9 @@ def main():
         }
         if multi:
             out["gather_ms_avg"] = gather_ms
+        out["scaling_note"] = ("ms_per_step / value: frames enqueued back to back (up to %d in flight); serial_ms_per_step / serial_value: every frame "
+                               "awaited, the reference's loop (src/app.ts:124-127).  BASELINE.json's >= 6x at 8 GPUs is claimed for the frames-in-flight "
+                               "figure; DESIGN.md 6 gives the emulated per-rank times for both." % FLIGHT)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         sys.stdout.flush()
