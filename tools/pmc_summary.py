@@ -66,7 +66,8 @@ def short(name):
 
 
 RAY_TRACE = re.compile(r"bvh_pixels|trace_pixels|trace_paths|first_bounce|trace_triangles|heatmap_triangles|trace_flow|trace_tiles")
-GATHER = re.compile(r"trace_triangles|heatmap_triangles|trace_flow|trace_tiles")      # reads are gathers: FETCH_SIZE x 1 (see above)
+GATHER = re.compile(r"trace_triangles|heatmap_triangles|trace_flow|trace_tiles|sky_resolve")      # reads are gathers: FETCH_SIZE x 1 (see above;
+# sky_resolve reads 16 bytes per lane at a 32-byte stride plus texel gathers: its raw FETCH_SIZE, 1.044 GB per C5 frame, is the size of its records, 1.062 GB)
 
 
 def summarise(files):
