@@ -88,6 +88,35 @@ def test_wrong_conventions_do_not_survive_the_comparison(ref, oracle):
     assert 0.7 < min(within1(r, sky.faces)) and max(within1(r, sky.faces)) == 1.0
 
 
+def test_sky_hypotheses_table_is_what_the_screenshot_says(ref):
+    """tests/golden/ref_pin.json["sky_hypotheses"] (tools/pin_sky_hypotheses.py): three readings the oracle fixes by convention
+    and the screenshot can speak to, each as the fraction of pure-sky pixels it reproduces exactly.  Re-derived here; what
+    the table shows is asserted: the GUI's minIntensity 0.3 with round-half-up is refuted, 0.3 with round-half-even does
+    worse than the fitted value under either rounding, 1/256 bilinear weights cannot be told from float weights, and the
+    camera's angles sit ON the 0.1-degree grid of the mouse handler (src/app.ts:28,173): a sharp optimum among its neighbours."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import pin_sky_hypotheses as P
+    scene, sky, W, H, B, canvas, pin = ref
+    table = P.main()
+    assert table == pin["sky_hypotheses"]
+    ex = {k: v["exact"] for k, v in table.items() if isinstance(v, dict) and "exact" in v}
+    base = [v for k, v in ex.items() if k.startswith("oracle:")][0]
+    assert base > 0.965
+    assert ex["(a) minIntensity 0.3 exactly, round-half-up"] < 0.70
+    assert 0.90 < ex["(a) minIntensity 0.3 exactly, round-half-even"] < base - 0.04
+    assert ex["fitted minIntensity, round-half-even"] == base                         # no ties at the fitted value
+    assert abs(ex["(b) fitted minIntensity, round-half-up, weights rounded to 1/256"] - base) < 0.001
+    assert abs(ex["(b) fitted minIntensity, round-half-up, weights truncated to 1/256"] - base) < 0.001
+    grid = [v for k, v in ex.items() if k.startswith("(d) camera angles on the 0.1-degree grid")][0]
+    assert grid >= base
+    nb = table["(d) exact fraction at the grid point and its eight neighbours"]
+    centre = nb["theta 106.8 phi -56.5"]
+    assert centre == grid and all(v < centre - 0.09 for k, v in nb.items() if k != "theta 106.8 phi -56.5")
+    best = table["best minIntensity on a 5e-5 grid, angles on the 0.1-degree grid, round-half-up"]
+    assert 0.2995 < best["minIntensity"] < 0.3 and best["exact"] > 0.975
+    assert all(v["within1"] == 1.0 for v in table.values() if isinstance(v, dict) and "within1" in v)
+
+
 @pytest.mark.gpu
 def test_reference_scene_on_the_gpu_bit_exact(ref, oracle):
     """The scene of the reference's screenshot through rt_write_triangles / _nodes / _blas / _tri_lookup /
