@@ -247,6 +247,8 @@ int rt_destroy(rt_ctx* c) {
         if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
     }
     if (c->ev_scene) (void)hipEventDestroy(c->ev_scene);
+    for (int v = 0; v < kVersions; ++v)
+        if (c->ev_ver[v]) (void)hipEventDestroy(c->ev_ver[v]);
     for (int k = 0; k < kStreams; ++k)
         if (c->streams[k]) (void)hipStreamDestroy(c->streams[k]);
     delete c;
@@ -838,9 +840,12 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     // Per-frame instance data (RR:169-192) travels with the frame: version `v` of the three buffers is brought to the
     // host's current state by a one-workgroup kernel whose kernarg block holds the values, in front of the ray-trace
     // kernel on the frame's stream.  The frame kVersions slots back read the same version: it must be through.
+    // Ordering does not lean on which stream a slot happens to use (a host may rotate rt_render_to over any number of its own
+    // streams): before a version is rewritten, EVERY frame in flight that reads it must be through; and a frame that reads a
+    // version another stream brought up to date waits for that update.
     const uint32_t v = slot % (uint32_t)kVersions;
     if (tri && c->ver_gen[v] != c->inst.gen) {
-        if (slot >= (uint32_t)kVersions) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[slot - (uint32_t)kVersions], 0));
+        for (uint32_t i = v; i < slot; i += (uint32_t)kVersions) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[i], 0));
         RtInstanceArgs ia;
         ia.nodes = static_cast<float*>(c->d_nodes[v].p);
         ia.blas = static_cast<float*>(c->d_blas[v].p);
@@ -852,8 +857,13 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         if (ia.n_blas_f) std::memcpy(ia.data + 31 * 8, c->inst.blas.data(), ia.n_blas_f * sizeof(float));
         if (ia.n_lookup_f) std::memcpy(ia.data + 31 * 8 + 16 * 20, c->inst.lookup.data(), ia.n_lookup_f * sizeof(float));
         RT_HIP(rt_launch_apply_instances(ia, s));
+        if (!c->ev_ver[v]) RT_HIP(hipEventCreateWithFlags(&c->ev_ver[v], hipEventDisableTiming));
+        RT_HIP(hipEventRecord(c->ev_ver[v], s));
+        c->ver_stream[v] = s;
         c->ver_gen[v] = c->inst.gen;
         ++c->stats.instance_uploads;
+    } else if (tri && c->ev_ver[v] && c->ver_stream[v] != s) {
+        RT_HIP(hipStreamWaitEvent(s, c->ev_ver[v], 0));
     }
     // tile order of the triangle kernel: only for frames on the library's own streams (each has its set of buffers)
     int order_set = -1;

@@ -155,7 +155,9 @@ int rt_comm_wait_frames(rt_ctx* c) {
         []() { std::this_thread::yield(); });
     if (hip_err != hipSuccess) return fail_hip(hip_err, "rt_wait: hipEventQuery");
     if (v == RtPollVerdict::Done) return RT_OK;
+    const bool earlier = s->poisoned && async == ncclSuccess;      // a call of this batch failed half way: no RCCL error to name
     abort_comm(c);
+    if (earlier) return fail(RT_ERR_COMM, "rt_wait: an exchange of this batch failed while it was being enqueued (see that call's error); communicator aborted");
     if (v == RtPollVerdict::Timeout) return fail(RT_ERR_COMM, "rt_wait: the frames did not complete within the communicator's deadline (rt_set_comm_timeout); communicator aborted");
     return fail_nccl(async, "rt_wait: asynchronous RCCL error; communicator aborted");
 }

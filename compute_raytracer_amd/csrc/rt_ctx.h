@@ -123,6 +123,8 @@ struct rt_ctx {
         uint64_t gen = 0;                        // bumped by every per-frame write
     } inst;
     uint64_t ver_gen[kVersions] = {0, 0, 0, 0};  // inst.gen each device version holds
+    hipEvent_t ev_ver[kVersions] = {nullptr};    // behind the apply_instances kernel that last brought the version up to date ...
+    hipStream_t ver_stream[kVersions] = {nullptr};   // ... on this stream
     size_t nodes_used = 0;                       // bytes of the node buffer written so far (any version)
     uint32_t node_count_max = 0;                 // largest u32(primitiveCount) of any node written so far (packed BLAS stack: <= 65535)
     // The persistent triangle kernel (rt_flow.hip) reads the BLAS trees from the library's relinked copy (rt_flow_build.h):

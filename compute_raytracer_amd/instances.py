@@ -106,7 +106,7 @@ def world_boxes(mats, box_lo, box_hi):
                       np.where(corner & 2, box_hi[:, 1], box_lo[:, 1]),
                       np.where(corner & 1, box_hi[:, 2], box_lo[:, 2])], axis=1)
         w = M[:, 3] * p[:, 0] + M[:, 7] * p[:, 1] + M[:, 11] * p[:, 2] + M[:, 15]
-        w = np.where(w == 0, 1.0, w)                               # `w = w || 1.0`
+        w = np.where((w == 0) | np.isnan(w), 1.0, w)               # `w = w || 1.0`: 0 and NaN are both falsy
         q = np.stack([(M[:, k] * p[:, 0] + M[:, 4 + k] * p[:, 1] + M[:, 8 + k] * p[:, 2] + M[:, 12 + k]) / w
                       for k in range(3)], axis=1).astype(F32).astype(np.float64)
         lo = np.minimum(lo, q)

@@ -271,7 +271,9 @@ int rt_comm_destroy(rt_ctx* ctx);      /* back to a single-GPU context (rank 0 o
  * the exchange kernels leave the device), rt_wait returns RT_ERR_COMM, and every later rt_render_gather /
  * rt_group_render on it returns RT_ERR_COMM at once.  The context stays valid for rt_comm_destroy,
  * rt_destroy and single-GPU rendering.  A host that wants to retry forms a new group (in a fresh child
- * process if the GPU itself is gone).  ms = 0 (default): no deadline, errors only. */
+ * process if the GPU itself is gone).  ms = 0 (default): no deadline, errors only.  The deadline bounds the whole rt_wait --
+ * the render kernels of the frames in flight AND their exchanges --, so it must be chosen above the slowest batch of frames the
+ * host enqueues (a full-size C5 frame renders for ~20 ms on one GPU): it is a liveness bound, not a latency target. */
 int rt_set_comm_timeout(rt_ctx* ctx, uint32_t ms);
 
 /* Collective; replaces RendererRaytracing.render()'s submit (RR:442-446, 465) for the whole group:
