@@ -194,8 +194,10 @@ class RendererRaytracing:
         return out
 
     def close(self):
+        """Destroys the context.  The pinned frames of host_frames() are freed too: arrays handed out by it must not be
+        used afterwards (copy what is to be kept)."""
         if self._ctx is not None:
-            self._lib.rt_destroy(self._ctx)
+            self._lib.rt_destroy(self._ctx)      # waits for every copy that was begun
             self._ctx = None
             for p in self._pinned:
                 self._lib.rt_host_free(p)

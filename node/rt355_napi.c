@@ -169,13 +169,15 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     return ext;
 }
 
+static void release_pending(napi_env env, rt_ctx* ctx);
 static napi_value Destroy(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
     handle* h = get_handle(env, argv[0], 0);
     if (!h) return NULL;
     if (h->parent) { napi_throw_error(env, "-5", "rt355: a group member is destroyed with its group (destroyGroup)"); return NULL; }
-    rt_destroy(h->ctx);
+    rt_destroy(h->ctx);                   /* waits for every copy that was begun */
+    release_pending(env, h->ctx);
     h->ctx = NULL;                        /* a second destroy, or any later use, throws */
     return undefined(env);
 }
@@ -581,8 +583,22 @@ static napi_value HostAlloc(napi_env env, napi_callback_info info) {
     return u8;
 }
 
-/* readPixelsAsync(ctx, framesBack, Uint8Array): the copy runs beside the rendering of the next frames; the array must
- * stay reachable until readPixelsWait(ctx) has returned */
+/* Destinations of copies that have been begun and not yet awaited: the addon holds a reference to each array, so that a
+ * script that drops its own cannot have the (pinned) memory freed under a running DMA; readPixelsWait releases them. */
+#define PENDING_MAX 64
+static struct { napi_ref ref; rt_ctx* ctx; } g_pending[PENDING_MAX];
+static int g_pending_n = 0;
+static void release_pending(napi_env env, rt_ctx* ctx) {
+    int k = 0;
+    for (int i = 0; i < g_pending_n; ++i) {
+        if (g_pending[i].ctx == ctx) napi_delete_reference(env, g_pending[i].ref);
+        else g_pending[k++] = g_pending[i];
+    }
+    g_pending_n = k;
+}
+
+/* readPixelsAsync(ctx, framesBack, Uint8Array): the copy runs beside the rendering of the next frames; the array stays
+ * referenced by the addon until readPixelsWait(ctx) has returned */
 static napi_value ReadPixelsAsync(napi_env env, napi_callback_info info) {
     napi_value argv[3];
     void* data; size_t len;
@@ -590,8 +606,18 @@ static napi_value ReadPixelsAsync(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 3, argv)) return NULL;
     rt_ctx* ctx = get_ctx(env, argv[0]);
     if (!ctx || !get_u32(env, argv[1], &back) || !get_typed(env, argv[2], napi_uint8_array, &data, &len)) return NULL;
+    if (g_pending_n == PENDING_MAX) {          /* more copies begun than anybody awaits: complete this context's, then go on */
+        int rcw = rt_read_pixels_wait(ctx);
+        if (rcw != RT_OK) return throw_status(env, rcw, ctx);
+        release_pending(env, ctx);
+        if (g_pending_n == PENDING_MAX) { napi_throw_error(env, NULL, "rt355: too many read-backs pending on other contexts"); return NULL; }
+    }
+    napi_ref ref;
+    if (napi_create_reference(env, argv[2], 1, &ref) != napi_ok) { napi_throw_error(env, NULL, "rt355: cannot reference the destination"); return NULL; }
     int rc = rt_read_pixels_async(ctx, back, (uint8_t*)data, len);
-    return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
+    if (rc != RT_OK) { napi_delete_reference(env, ref); return throw_status(env, rc, ctx); }
+    g_pending[g_pending_n].ref = ref; g_pending[g_pending_n].ctx = ctx; ++g_pending_n;
+    return undefined(env);
 }
 
 static napi_value ReadPixelsWait(napi_env env, napi_callback_info info) {
@@ -600,6 +626,7 @@ static napi_value ReadPixelsWait(napi_env env, napi_callback_info info) {
     rt_ctx* ctx = get_ctx(env, argv[0]);
     if (!ctx) return NULL;
     int rc = rt_read_pixels_wait(ctx);
+    release_pending(env, ctx);
     return rc == RT_OK ? undefined(env) : throw_status(env, rc, ctx);
 }
 
