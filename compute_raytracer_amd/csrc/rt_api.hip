@@ -29,26 +29,6 @@ thread_local int g_rt_kernel_id = 0;
 // unchanged sphere count posts the new records here; frames meanwhile use the OLD topology with node
 // bounds refitted on the device (rt_bvh.hip: bvh_refit) -- always valid, only looser as spheres drift --
 // and the next frame that follows a sphere write after the worker has finished takes the new one.
-// The hierarchy of a sphere scene: one sphere per leaf while that leaves room for two workgroups per CU (six waves per SIMD,
-// rt_bvh.hip: launch_bvh); beyond, leaves of up to four spheres IF that brings the node count back under the limit (C5: 5,530
-// nodes -> about 2,700).  -> nodes; group: 1 or 4.
-static uint32_t build_hierarchy(const float* records, uint32_t n, std::vector<float>& rec, std::vector<uint32_t>& link,
-                                std::vector<uint32_t>& members, std::vector<uint32_t>& mrange, uint32_t& group) {
-    static const uint32_t limit = rt_bvh_nodes_for_two_workgroups();
-    group = 1u;
-    uint32_t nodes = rt_bvh_build_grouped(records, n, 1u, rec, link, nullptr, nullptr);
-    members.clear(); mrange.clear();
-#ifdef RT355_DEV_EXPORTS
-    if (getenv("RT355_BVH_NOGROUP")) return nodes;
-#endif
-    if (nodes > limit) {
-        std::vector<float> r4; std::vector<uint32_t> l4, m4, g4;
-        const uint32_t n4 = rt_bvh_build_grouped(records, n, 4u, r4, l4, &m4, &g4);
-        if (n4 <= limit && !m4.empty()) { rec.swap(r4); link.swap(l4); members.swap(m4); mrange.swap(g4); nodes = n4; group = 4u; }
-    }
-    return nodes;
-}
-
 struct rt_rebuild {
     std::thread th;
     std::mutex m;
@@ -57,12 +37,12 @@ struct rt_rebuild {
     std::vector<float> in_records;            // job (latest posted wins)
     uint32_t in_n = 0;
     std::vector<float> out_rec;               // result
-    std::vector<uint32_t> out_link, out_members, out_mrange;
-    uint32_t out_n = 0, out_nodes = 0, out_group = 1;
+    std::vector<uint32_t> out_link;
+    uint32_t out_n = 0, out_nodes = 0;
 
     void run() {
         std::vector<float> records, rec;
-        std::vector<uint32_t> link, members, mrange;
+        std::vector<uint32_t> link;
         for (;;) {
             uint32_t n;
             {
@@ -73,16 +53,12 @@ struct rt_rebuild {
                 n = in_n;
                 pending = false;
             }
-            uint32_t group = 1;
-            const uint32_t nodes = build_hierarchy(records.data(), n, rec, link, members, mrange, group);
+            const uint32_t nodes = rt_bvh_build(records.data(), n, rec, link);
             std::lock_guard<std::mutex> lk(m);
             out_rec.swap(rec);
             out_link.swap(link);
-            out_members.swap(members);
-            out_mrange.swap(mrange);
             out_n = n;
             out_nodes = nodes;
-            out_group = group;
             ready = true;
         }
     }
@@ -257,7 +233,6 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
-    (void)hipFree(c->d_bvh_members); (void)hipFree(c->d_bvh_mrange); (void)hipFree(c->d_geo_m);
     for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex, &c->d_corners, &c->d_flow}) (void)hipFree(b->p);
     for (int k = 0; k < kStreams; ++k) (void)hipFree(c->d_flow_ovf[k].p);
     for (int k = 0; k < kStreams; ++k) { (void)hipFree(c->d_tile_cost[k].p); (void)hipFree(c->d_tile_order[k].p); }
@@ -680,16 +655,13 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         if (rc != RT_OK) return rc;
         uint32_t nodes = c->bvh_nodes;
         if (!refit) {
-            nodes = build_hierarchy(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link, c->h_bvh_members, c->h_bvh_mrange, c->bvh_group);
+            nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link);
             upload_topology = true;
         } else if (c->rebuild) {
             std::lock_guard<std::mutex> lk(c->rebuild->m);
             if (c->rebuild->ready && c->rebuild->out_n == c->n) {
                 c->h_bvh_rec.swap(c->rebuild->out_rec);
                 c->h_bvh_link.swap(c->rebuild->out_link);
-                c->h_bvh_members.swap(c->rebuild->out_members);
-                c->h_bvh_mrange.swap(c->rebuild->out_mrange);
-                c->bvh_group = c->rebuild->out_group;
                 nodes = c->rebuild->out_nodes;
                 upload_topology = true;
             }
@@ -701,14 +673,6 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_rec), ((size_t)nodes + 1u) * sizeof(float4)));
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_link), ((size_t)nodes + 1u) * sizeof(uint32_t)));
             c->bvh_cap = nodes + 1u;
-        }
-        if (c->bvh_group > 1u && (c->n > c->members_cap || nodes + 1u > c->mrange_cap)) {      // grouped leaves: member list, ranges, records in leaf order
-            (void)hipFree(c->d_bvh_members); (void)hipFree(c->d_bvh_mrange); (void)hipFree(c->d_geo_m);
-            c->d_bvh_members = nullptr; c->d_bvh_mrange = nullptr; c->d_geo_m = nullptr; c->members_cap = c->mrange_cap = 0;
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_members), (size_t)c->n * sizeof(uint32_t)));
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_geo_m), (size_t)c->n * sizeof(float4)));
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_mrange), ((size_t)nodes + 1u) * 2u * sizeof(uint32_t)));
-            c->members_cap = c->n; c->mrange_cap = nodes + 1u;
         }
         c->bvh_nodes = nodes;
     }
@@ -816,19 +780,12 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             const size_t nn = (size_t)c->bvh_nodes + 1u;
             RT_HIP(hipMemcpyAsync(c->d_bvh_rec, c->h_bvh_rec.data(), nn * sizeof(float4), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemcpyAsync(c->d_bvh_link, c->h_bvh_link.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            if (c->bvh_group > 1u) {
-                RT_HIP(hipMemcpyAsync(c->d_bvh_members, c->h_bvh_members.data(), (size_t)c->n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-                RT_HIP(hipMemcpyAsync(c->d_bvh_mrange, c->h_bvh_mrange.data(), nn * 2u * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            }
             RT_HIP(hipStreamSynchronize(s));   // pageable sources: the vectors may be rebuilt later
             c->bvh_topo_n = c->n;
         }
-        const bool grouped = c->bvh_group > 1u;
         // bounds of the inner nodes for the current positions (a topology from the worker was built for older ones)
-        if (refit) RT_HIP(rt_launch_bvh_refit(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, c->d_records, grouped ? c->d_bvh_mrange : nullptr,
-                                              grouped ? c->d_bvh_members : nullptr, s));
-        RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, fa.geo_f, grouped ? c->d_bvh_members : nullptr, s));
-        if (grouped) RT_HIP(rt_launch_bvh_members(c->d_geo_m, fa.geo, c->d_bvh_members, c->n, s));
+        if (refit) RT_HIP(rt_launch_bvh_refit(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, c->d_records, s));
+        RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, fa.geo_f, s));
         c->bvh_valid = true;
     }
     if (need_prep || need_bvh) {
@@ -838,9 +795,6 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     fa.bvh_rec = use_bvh ? c->d_bvh_rec : nullptr;
     fa.bvh_link = use_bvh ? c->d_bvh_link : nullptr;
     fa.bvh_nodes = use_bvh ? c->bvh_nodes : 0u;
-    fa.bvh_group = use_bvh ? c->bvh_group : 1u;
-    fa.geo_m = (use_bvh && c->bvh_group > 1u) ? c->d_geo_m : nullptr;
-    fa.id_m = (use_bvh && c->bvh_group > 1u) ? c->d_bvh_members : nullptr;
     // frames in flight on DIFFERENT streams run concurrently and share the chip: this frame's grid is
     // 1 / (number of distinct streams among it and the kStreams-1 frames enqueued before it)
     c->slot_stream[slot] = s;
@@ -1196,23 +1150,6 @@ int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* 
     if (cap_nodes < nodes + 1u || !rec4 || !link) return fail(RT_ERR_CAPACITY, "rt_build_hierarchy: need n_nodes + 1 entries");
     std::memcpy(rec4, r.data(), r.size() * sizeof(float));
     std::memcpy(link, l.data(), l.size() * sizeof(uint32_t));
-    return RT_OK;
-}
-
-int rt_build_hierarchy_grouped(const float* records, uint32_t n, uint32_t group, float* rec4, uint32_t* link, uint32_t* members,
-                               uint32_t* mrange, uint32_t cap_nodes, uint32_t* n_nodes) {
-    if ((n && !records) || !n_nodes) return fail(RT_ERR_INVALID_ARG, "rt_build_hierarchy_grouped: NULL argument");
-    if (group < 2u || group > 4u) return fail(RT_ERR_INVALID_ARG, "rt_build_hierarchy_grouped: group must be 2, 3 or 4");
-    std::vector<float> r;
-    std::vector<uint32_t> l, m, g;
-    const uint32_t nodes = rt_bvh_build_grouped(records, n, group, r, l, &m, &g);
-    *n_nodes = nodes;
-    if (l.empty()) return RT_OK;
-    if (cap_nodes < nodes + 1u || !rec4 || !link || !members || !mrange) return fail(RT_ERR_CAPACITY, "rt_build_hierarchy_grouped: need n_nodes + 1 entries");
-    std::memcpy(rec4, r.data(), r.size() * sizeof(float));
-    std::memcpy(link, l.data(), l.size() * sizeof(uint32_t));
-    std::memcpy(members, m.data(), m.size() * sizeof(uint32_t));
-    std::memcpy(mrange, g.data(), g.size() * sizeof(uint32_t));
     return RT_OK;
 }
 

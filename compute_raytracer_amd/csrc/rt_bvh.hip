@@ -143,19 +143,11 @@ __host__ __device__ inline uint32_t bvh_lds_lists(uint32_t n_nodes, uint32_t bas
 }
 
 // ---- device: leaf records = the filter records prep_spheres wrote ------------------------------------
-// id_m != null: grouped hierarchy -- a leaf of ONE sphere takes that sphere's filter record, a leaf of several keeps its bound
-__global__ void bvh_fill_leaves(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, const uint32_t* id_m) {
+__global__ void bvh_fill_leaves(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const uint32_t l = link[i];
-    if (!(l & 0x80000000u)) return;
-    if (!id_m) rec[i] = geo_f[l & 0x7FFFFFFFu];
-    else if (((l >> 24) & 3u) == 0u) rec[i] = geo_f[id_m[l & 0x00FFFFFFu]];
-}
-// exact records in leaf order, for the literal evaluation of grouped leaves
-__global__ void bvh_members(float4* geo_m, const float4* geo, const uint32_t* id_m, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) geo_m[i] = geo[id_m[i]];
+    if (l & 0x80000000u) rec[i] = geo_f[l & 0x7FFFFFFFu];
 }
 
 // ---- device: node bounds for moved spheres (same topology) ----------------------------------------------
@@ -181,25 +173,17 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 }
 
 __global__ __launch_bounds__(256) void bvh_refit(float4* __restrict__ rec, const uint32_t* __restrict__ link,
-                                                  uint32_t n_nodes, const float* __restrict__ records,
-                                                  const uint32_t* __restrict__ mrange, const uint32_t* __restrict__ id_m) {
+                                                  uint32_t n_nodes, const float* __restrict__ records) {
     const uint32_t node = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (node >= n_nodes) return;
     const uint32_t lk = link[node];
-    // leaves of one sphere are filled from the filter records (bvh_fill_leaves); a grouped leaf is bounded like an inner node
-    if ((lk & 0x80000000u) && (!mrange || ((lk >> 24) & 3u) == 0u)) return;
-    // the members: the leaves of the subtree, nodes (node, end) -- or, grouped, positions [first, end) of the leaf-order list
-    const uint32_t first = mrange ? mrange[2u * node] : node + 1u, end = mrange ? first + mrange[2u * node + 1u] : lk >> 2;
-    auto sphere = [&](uint32_t j, double c[3], double& r) -> bool {     // member j of this lane's stride, if it is one
+    if (lk & 0x80000000u) return;                       // leaves are filled from the filter records (bvh_fill_leaves)
+    const uint32_t first = node + 1u, end = lk >> 2;     // the subtree: nodes (node, end)
+    auto sphere = [&](uint32_t j, double c[3], double& r) -> bool {     // member j of this lane's stride, if it is a leaf
         if (j >= end) return false;
-        uint32_t sid;
-        if (mrange) sid = id_m[j];
-        else {
-            const uint32_t l = link[j];
-            if (!(l & 0x80000000u)) return false;
-            sid = l & 0x7FFFFFFFu;
-        }
-        const float* s = records + 8u * (size_t)sid;
+        const uint32_t l = link[j];
+        if (!(l & 0x80000000u)) return false;
+        const float* s = records + 8u * (size_t)(l & 0x7FFFFFFFu);
         for (int a = 0; a < 3; ++a) { const double v = (double)s[a]; c[a] = v == v ? v : 0.0; }   // NaN orders as 0 (host build)
         const double rv = fabs((double)s[7]);
         r = rv == rv ? rv : 0.0;
@@ -308,11 +292,9 @@ __device__ __forceinline__ void reversed_shadow_walk(bool shadow, v3 L, float li
 // completed and fewer than TAIL lanes are still walking, the call returns; the stragglers resume
 // in the next call, next to the fresh rays of the lanes that completed -- the long tail of a
 // wave's slowest rays no longer holds 64 lanes for a handful.
-// GROUP: leaves of several spheres (rt_bvh_build.h: grouped) -- a candidate entry is (count - 1) << 24 | first position in the
-// leaf-order arrays geo (= A.geo_m) / id_m, and the pooled evaluation tests every member of it.
-template <bool SGN, bool NLDS, int CAP, bool ROOMY, bool GROUP>
+template <bool SGN, bool NLDS, int CAP, bool ROOMY>
 __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
-                                          const float4* __restrict__ geo, const uint32_t* __restrict__ id_m, uint32_t* slot, unsigned long long* best,
+                                          const float4* __restrict__ geo, uint32_t* slot, unsigned long long* best,
                                           uint32_t& i, v3 o, v3 d, v3 wo, v3 wd, float madd, float& nearest, int& idx
 #ifdef RT_BVH_COUNT
                                           , uint32_t& steps_acc
@@ -363,39 +345,10 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
             uint32_t e = 0;
             if (k < cnt) e = slot[k * 64u];                              // every lane reads row k before any lane writes
             const uint32_t pos = total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (k < cnt) pool[pos] = GROUP ? ((lane << 26) | (e & 0x03FFFFFFu)) : ((lane << 24) | (e & 0x00FFFFFFu));   // pos < 64 (k + 1): rows > k are untouched
+            if (k < cnt) pool[pos] = (lane << 24) | (e & 0x00FFFFFFu);   // pos < 64 (k + 1): rows > k are untouched
             total += (uint32_t)__popcll(m);
         }
         best[lane] = ((unsigned long long)__float_as_uint(nearest) << 32) | (unsigned long long)(uint32_t)idx;
-        if (GROUP) {
-            for (uint32_t i = lane; __ballot(i < total) != 0ull; i += 64u) {
-                const uint32_t e = i < total ? pool[i] : (lane << 26);
-                const int owner = (int)(e >> 26);
-                const uint32_t first = e & 0x00FFFFFFu, members = ((e >> 24) & 3u) + 1u;
-                const v3 oo = V(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
-                const v3 od = V(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
-                const float a2 = dot(od, od);                         // HK:308
-                // all members' records are requested before the first is evaluated: one round trip per item, not one per member
-                float4 g4[4];
-#pragma unroll
-                for (uint32_t mi = 0; mi < 4u; ++mi) g4[mi] = geo[first + (mi < members ? mi : 0u)];
-#pragma unroll
-                for (uint32_t mi = 0; mi < 4u; ++mi) {
-                    if (i < total && mi < members) {
-                        const float4 g = g4[mi];
-                        const v3 oc = sub(oo, V(g.x, g.y, g.z));
-                        const float b = 2.0f * dot(od, oc);               // HK:309
-                        const float c = dot(oc, oc) - g.w;                // HK:310
-                        const float disc = b * b - (4.0f * a2) * c;       // HK:311
-                        if (disc > 0.0f && b < 0.0f) {                    // HK:316; b >= 0 gives t <= 0
-                            const float t = (-b - sqrtf(disc)) / (2.0f * a2);   // HK:317
-                            if (t > 0.001f && t < 9999.0f)                // HK:318 with tMin / the initial tMax of RK:315, RK:172
-                                atomicMin(&best[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)id_m[first + mi]);
-                        }
-                    }
-                }
-            }
-        } else
         for (uint32_t i = lane; __ballot(i < total) != 0ull; i += 64u) {
 #ifdef RT_BVH_COUNT
             if (RT_BVH_COUNT == 4) g_steps += lane == 0u ? 1u : 0u;                    // drain iterations (wave)
@@ -534,7 +487,7 @@ inline bool lds_fits(size_t k, size_t bytes) { return k * ((bytes + 1279u) / 128
 // chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
 // workgroups serve scenes whose nodes leave room for one workgroup per CU only (4 waves per SIMD).
 // FLAT: compiled for a one-colour 1x1 sky (A.sky_flat; C1-C4) -- no cube filtering code in the kernel.
-template <int WAVES, bool SGN, bool NLDS, int CAP, bool FLAT, bool GROUP = false>
+template <int WAVES, bool SGN, bool NLDS, int CAP, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
@@ -690,10 +643,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
         else if (shadow) wo = sc.lightPos;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
-        trace_bvh<SGN, NLDS, CAP, WAVES == 16, GROUP>(A.bvh_tail, R, L, n, GROUP ? A.geo_m : A.geo, A.id_m, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx, nrays);
+        trace_bvh<SGN, NLDS, CAP, WAVES == 16>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx, nrays);
         if (walking && node == n) {
 #else
-        trace_bvh<SGN, NLDS, CAP, WAVES == 16, GROUP>(A.bvh_tail, R, L, n, GROUP ? A.geo_m : A.geo, A.id_m, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx);
+        trace_bvh<SGN, NLDS, CAP, WAVES == 16>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx);
         if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
 #endif
@@ -805,7 +758,7 @@ __global__ __launch_bounds__(256) void sky_resolve(const RtFrameArgs A) {
     }
 }
 
-template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL, bool GROUP = false>
+template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
 hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     // The walk is left for the shading pass once fewer than `tail` lanes still walk.  A frame that has the
     // chip to itself prefers a lower threshold than frames that share it (C3, tools/knob_ab.py: one frame at a
@@ -820,7 +773,7 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_TAIL")) a.bvh_tail = (uint32_t)atoi(e);
 #endif
-    auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, true, GROUP> : bvh_pixels<WAVES, SGN, NLDS, CAP, false, GROUP>;
+    auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, true> : bvh_pixels<WAVES, SGN, NLDS, CAP, false>;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -869,17 +822,6 @@ hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     // per wave: CAP x 64 candidate entries + 64 eight-byte slots of running nearest hits.  Scenes whose nodes
     // leave room for one 16-wave workgroup only (C5: 128 KB of nodes) get six-entry lists: 2 KB per wave again.
     constexpr size_t per_wave = (size_t)CAP * 256u + 512u, per_wave6 = 6u * 256u + 512u;
-    if (a.bvh_group > 1u) {
-        // grouped leaves (the host rebuilt the hierarchy with them because one sphere per leaf left room for one workgroup per
-        // CU only): half the nodes -- the forms with six waves per SIMD again
-        if (!a.geo_m || !a.id_m) return hipErrorInvalidValue;
-        if (lds_fits(3u, nodes + 8u * per_wave)) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL, true>(a, nodes + 8u * per_wave, s);
-        if (lds_fits(2u, nodes + 12u * per_wave)) return launch_bvh_as<12, SGN, true, CAP, RT_BVH_TAIL_SMALL, true>(a, nodes + 12u * per_wave, s);
-        if (lds_fits(2u, nodes + 12u * per_wave6)) return launch_bvh_as<12, SGN, true, 6, RT_BVH_TAIL_SMALL, true>(a, nodes + 12u * per_wave6, s);
-        if (nodes + 16u * per_wave <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE, true>(a, nodes + 16u * per_wave, s);
-        if (nodes + 16u * per_wave6 <= cap)    return launch_bvh_as<16, SGN, true, 6, RT_BVH_TAIL_LARGE, true>(a, nodes + 16u * per_wave6, s);
-        return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE, true>(a, 1024u + 8u * per_wave, s);
-    }
     if (lds_fits(3u, nodes + 8u * per_wave)) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, nodes + 8u * per_wave, s);
     // two 12-wave workgroups per CU keep six waves per SIMD for scenes between the two forms (~1100-1500 spheres:
     // 1200 / 1400 / 1500 spheres at 4K 2.58 / 2.83 / 2.88 -> 2.32 / 2.55 / 2.59 ms per frame in flight; with six-entry
@@ -910,32 +852,14 @@ hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     return a.signed_filter ? rtk::launch_bvh<true>(a, s) : rtk::launch_bvh<false>(a, s);
 }
 
-hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, const uint32_t* mrange, const uint32_t* id_m, hipStream_t s) {
+hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtk::bvh_refit, dim3((n_nodes + 3u) / 4u), dim3(256), 0, s, rec, link, n_nodes, records, mrange, id_m);
+    hipLaunchKernelGGL(rtk::bvh_refit, dim3((n_nodes + 3u) / 4u), dim3(256), 0, s, rec, link, n_nodes, records);
     return hipGetLastError();
 }
 
-hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, const uint32_t* id_m, hipStream_t s) {
+hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtk::bvh_fill_leaves, dim3((n_nodes + 255u) / 256u), dim3(256), 0, s, rec, link, n_nodes, geo_f, id_m);
+    hipLaunchKernelGGL(rtk::bvh_fill_leaves, dim3((n_nodes + 255u) / 256u), dim3(256), 0, s, rec, link, n_nodes, geo_f);
     return hipGetLastError();
-}
-
-hipError_t rt_launch_bvh_members(float4* geo_m, const float4* geo, const uint32_t* id_m, uint32_t n, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtk::bvh_members, dim3((n + 255u) / 256u), dim3(256), 0, s, geo_m, geo, id_m, n);
-    return hipGetLastError();
-}
-
-// The largest hierarchy (nodes) the six-waves-per-SIMD forms of bvh_pixels hold in LDS: two 12-wave workgroups per CU with
-// six-entry lists.  The host rebuilds a larger one with grouped leaves (rt_api.hip).
-uint32_t rt_bvh_nodes_for_two_workgroups() {
-    constexpr size_t per_wave6 = 6u * 256u + 512u;
-    uint32_t lo = 0, hi = 1u << 20;
-    while (lo + 1u < hi) {                      // largest n with lds_fits(2, lists(n) + 12 per_wave6)
-        const uint32_t mid = (lo + hi) / 2u;
-        if (rtk::lds_fits(2u, (size_t)rtk::bvh_lds_lists(mid, 0u) + 12u * per_wave6)) lo = mid; else hi = mid;
-    }
-    return lo;
 }

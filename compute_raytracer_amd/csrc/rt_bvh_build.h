@@ -26,12 +26,6 @@ struct Builder {
     std::vector<float>& out_rec;   // 4 floats per node
     std::vector<uint32_t>& out_link;
     std::vector<uint32_t> ids;
-    // Grouped leaves (group > 1; rt_bvh_build_grouped): a leaf holds up to `group` spheres under ONE bound -- the node test decides
-    // for all of them, a passing leaf hands all of them to the literal evaluation.  Half the nodes, a shorter walk, more
-    // candidates: for scenes whose one-sphere-per-leaf hierarchy leaves room for one workgroup per CU only (rt_bvh.hip).
-    uint32_t group = 1;
-    std::vector<uint32_t>* members = nullptr;    // sphere ids in leaf order; a leaf's link names (count - 1) << 24 | first position
-    std::vector<uint32_t>* mrange = nullptr;     // per node: first member position, member count (what bvh_refit_grouped bounds)
 
     // NaN coordinates order as 0 (a sphere with a NaN in it can never be hit: every comparison of the
     // literal test is false), so that the sorts below keep a strict weak ordering on any input
@@ -46,22 +40,7 @@ struct Builder {
 
     void leaf(uint32_t sphere) {
         out_rec.insert(out_rec.end(), {0.0f, 0.0f, 0.0f, 0.0f});   // filled on the device from geo_f
-        if (group > 1u) {
-            out_link.push_back(0x80000000u | (uint32_t)members->size());
-            mrange->push_back((uint32_t)members->size()); mrange->push_back(1u);
-            members->push_back(sphere);
-        } else {
-            out_link.push_back(0x80000000u | sphere);
-        }
-    }
-    // ids[lo,hi), 2 ... group of them, as one leaf: its record is their bound (like an inner node's)
-    void leaf_group(uint32_t lo, uint32_t hi) {
-        float b[4];
-        bound(lo, hi, b);
-        out_rec.insert(out_rec.end(), b, b + 4);
-        out_link.push_back(0x80000000u | ((hi - lo - 1u) << 24) | (uint32_t)members->size());
-        mrange->push_back((uint32_t)members->size()); mrange->push_back(hi - lo);
-        for (uint32_t k = lo; k < hi; ++k) members->push_back(ids[k]);
+        out_link.push_back(0x80000000u | sphere);
     }
 
     // Splits ids[lo,hi) in two.  Up to 32768 members: the position, over all three axes, that
@@ -111,12 +90,8 @@ struct Builder {
             };
             for (uint32_t k = n; k-- > 1u;) suffix[k] = grow(order[k]) * (double)(n - k);   // members k..n-1
             for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
-            // grouped leaves: near the leaves (up to 64 leaves' worth of spheres) a range is cut at multiples of the leaf
-            // size only, so that leaves come out full -- 4,096 spheres: 1,400 nodes instead of 2,700 with ragged leaves
-            const bool whole = group > 1u && n > group && n <= 64u * group;
             for (uint32_t k = 1; k < n; ++k) {                                              // members 0..k-1 | k..n-1
                 const double cost = grow(order[k - 1u]) * (double)k + suffix[k];
-                if (whole && k % group != 0u) continue;
                 if (cost < best) { best = cost; best_ax = ax; best_k = k; }
             }
         }
@@ -186,11 +161,9 @@ struct Builder {
 
     void emit(uint32_t lo, uint32_t hi) {
         if (hi - lo == 1u) { leaf(ids[lo]); return; }
-        if (group > 1u && hi - lo <= group) { leaf_group(lo, hi); return; }
         const size_t me = out_link.size();
         out_rec.insert(out_rec.end(), {0.0f, 0.0f, 0.0f, 0.0f});
         out_link.push_back(0u);
-        if (group > 1u) { mrange->push_back((uint32_t)members->size()); mrange->push_back(hi - lo); }
         children(lo, hi);
         float b[4];
         bound(lo, hi, b);
@@ -200,11 +173,10 @@ struct Builder {
 
     // up to four children: the largest part is split until there are four
     void children(uint32_t lo, uint32_t hi) {
-        if (hi - lo <= 4u && (group <= 1u || hi - lo == 1u)) {
+        if (hi - lo <= 4u) {
             for (uint32_t k = lo; k < hi; ++k) leaf(ids[k]);
             return;
         }
-        if (group > 1u && hi - lo <= group) { leaf_group(lo, hi); return; }     // (top level only: emit() catches the rest)
         uint32_t cut[5] = {lo, hi, 0, 0, 0};     // sorted part boundaries
         int parts = 1;
         while (parts < 4) {
@@ -227,18 +199,11 @@ struct Builder {
 // sphere) as leaves of their own -- inside a node they would inflate it to cover everything --,
 // then up to four subtrees over the rest.  Returns the node count n; the arrays hold n + 1
 // entries, the last one being the sentinel the traversal loop parks finished lanes on.
-// group > 1: leaves of up to `group` spheres (at most 4: the count travels in two bits of the link); `members` receives the
-// sphere ids in leaf order, `mrange` per node {first member position, member count}.
-inline uint32_t rt_bvh_build_grouped(const float* records, uint32_t n, uint32_t group, std::vector<float>& rec4, std::vector<uint32_t>& link,
-                                     std::vector<uint32_t>* members, std::vector<uint32_t>* mrange) {
+inline uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4, std::vector<uint32_t>& link) {
     rec4.clear(); link.clear();
-    if (members) members->clear();
-    if (mrange) mrange->clear();
     if (n == 0) return 0;
     rec4.reserve((size_t)n * 6u); link.reserve((size_t)n * 3u / 2u + 8u);
     Builder b{records, rec4, link, {}};
-    if (group > 4u) group = 4u;
-    if (group > 1u && members && mrange && n < (1u << 24)) { b.group = group; b.members = members; b.mrange = mrange; }
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = 0; i < n; ++i)
         for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.cx(i, a)); mx[a] = std::max(mx[a], b.cx(i, a)); }
@@ -257,11 +222,6 @@ inline uint32_t rt_bvh_build_grouped(const float* records, uint32_t n, uint32_t 
     const uint32_t nodes = (uint32_t)link.size();
     rec4.insert(rec4.end(), {0.0f, 0.0f, 0.0f, INFINITY});   // sentinel [nodes]: never passes, links to itself
     link.push_back(4u * nodes);
-    if (b.group > 1u) { mrange->push_back(0u); mrange->push_back(0u); }
     return nodes;
-}
-
-inline uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4, std::vector<uint32_t>& link) {
-    return rt_bvh_build_grouped(records, n, 1u, rec4, link, nullptr, nullptr);
 }
 

@@ -76,12 +76,6 @@ struct rt_ctx {
     std::vector<float> h_records;
     std::vector<float> h_bvh_rec;
     std::vector<uint32_t> h_bvh_link;
-    std::vector<uint32_t> h_bvh_members, h_bvh_mrange;   // grouped leaves (bvh_group > 1): sphere ids in leaf order; per node {first, count}
-    uint32_t bvh_group = 1;
-    uint32_t* d_bvh_members = nullptr;
-    uint32_t* d_bvh_mrange = nullptr;
-    float4* d_geo_m = nullptr;             // exact records in leaf order
-    uint32_t members_cap = 0, mrange_cap = 0;
     float4* d_bvh_rec = nullptr;
     uint32_t* d_bvh_link = nullptr;
     uint32_t bvh_cap = 0, bvh_nodes = 0;

@@ -72,10 +72,6 @@ struct RtFrameArgs {
     uint32_t bvh_nodes;        // 0: no hierarchy built
     uint32_t grid_share;       // >1: this frame's persistent grid takes 1/grid_share of the chip (frames in flight)
     uint32_t bvh_tail;         // lanes still walking below which a wave leaves the walk for the shading pass (0: never)
-    // grouped leaves (bvh_group > 1; rt_bvh_build.h): a leaf's link is 0x80000000 | (count - 1) << 24 | first position in id_m
-    uint32_t bvh_group;        // 1: a leaf is one sphere and its link names it
-    const float4* geo_m;       // [N] exact records {c, r*r} in leaf order: geo[id_m[k]]
-    const uint32_t* id_m;      // [N] sphere index at leaf-order position k
 };
 
 struct RtPrepArgs {
@@ -108,11 +104,7 @@ hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
 hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s);
 hipError_t rt_launch_sky_resolve(const RtFrameArgs& a, hipStream_t s);   // textured sky: composes the end-of-path records in a.fin (rt_bvh.hip)
-// mrange / id_m: grouped hierarchy (per node {first member position, count}, sphere ids in leaf order); null: one sphere per leaf
-hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, const uint32_t* mrange, const uint32_t* id_m, hipStream_t s);
-hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, const uint32_t* id_m, hipStream_t s);
-hipError_t rt_launch_bvh_members(float4* geo_m, const float4* geo, const uint32_t* id_m, uint32_t n, hipStream_t s);
-// nodes the LDS forms of bvh_pixels have room for (two 12-wave workgroups per CU with six-entry lists): a larger hierarchy is rebuilt with grouped leaves
-uint32_t rt_bvh_nodes_for_two_workgroups();
+hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, hipStream_t s);
+hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t W, uint32_t H,
                               uint32_t world, uint32_t padded_tiles, hipStream_t s);

@@ -319,14 +319,6 @@ int rt_group_wait(rt_group* g);
 int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* link, uint32_t cap_nodes,
                        uint32_t* n_nodes);
 
-/* The same build with GROUPED leaves, as the library uses it for scenes whose one-sphere-per-leaf hierarchy would leave room for
- * one workgroup per CU only: a leaf holds up to `group` (2 ... 4) spheres under one bound; its link is
- * 0x80000000 | (count - 1) << 24 | first, `first` a position in `members` (n sphere indices in leaf order); `mrange` receives
- * per node {first member position, member count} (2 (n_nodes + 1) words).  A leaf of ONE sphere has a zero record (the device
- * fills it from the sphere's filter record), a leaf of several carries its bound like an inner node. */
-int rt_build_hierarchy_grouped(const float* records, uint32_t n, uint32_t group, float* rec4, uint32_t* link, uint32_t* members,
-                               uint32_t* mrange, uint32_t cap_nodes, uint32_t* n_nodes);
-
 /* Runs the HOST side of the persistent triangle kernel on its own (no device, no context): the relinked copy of the BLAS
  * trees it walks.  `nodes`: the node buffer as rt_write_nodes receives it (8 f32 per node); `roots`: the
  * rootNodeIndex of every instance.  Writes *n_pairs records of 16 words {c1.min.xyz, meta1, c1.max.xyz, 0, c2.min.xyz, meta2,

@@ -114,58 +114,3 @@ def test_build_is_deterministic_and_reports_capacity():
     rc = abi.load().rt_build_hierarchy(rec.ctypes.data_as(fp), rec.shape[0], small.ctypes.data_as(fp),
                                        link.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 8, ctypes.byref(nodes))
     assert rc == abi.RT_ERR_CAPACITY and nodes.value == a[3]
-
-
-# ---- grouped leaves (round 4): up to four spheres under one leaf bound ----------------------------------------------------
-def build_grouped(spheres, group):
-    rec = np.ascontiguousarray(rt.SceneRaytracing().createScene(spheres).pack_spheres(), dtype=np.float32).reshape(-1, 8)
-    n = rec.shape[0]
-    cap = 2 * n + 64
-    out = np.zeros((cap, 4), np.float32)
-    link = np.zeros(cap, np.uint32)
-    members = np.zeros(n, np.uint32)
-    mrange = np.zeros((cap, 2), np.uint32)
-    nodes = ctypes.c_uint32(0)
-    fp, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)
-    rc = abi.load().rt_build_hierarchy_grouped(rec.ctypes.data_as(fp), n, group, out.ctypes.data_as(fp), link.ctypes.data_as(up),
-                                               members.ctypes.data_as(up), mrange.ctypes.data_as(up), cap, ctypes.byref(nodes))
-    assert rc == abi.RT_OK
-    m = nodes.value
-    return rec, out[: m + 1].copy(), link[: m + 1].copy(), members, mrange[: m + 1].copy(), m
-
-
-@pytest.mark.parametrize("n,seed,group", [(5, 2, 4), (64, 357, 2), (1024, 358, 4), (4096, 360, 4), (4096, 360, 3), (700, 5, 4)])
-def test_grouped_leaves(n, seed, group):
-    rec, out, link, members, mrange, m = build_grouped(synthetic_spheres(n, seed), group)
-    assert sorted(members.tolist()) == list(range(n))                            # every sphere in exactly one leaf
-    assert link[m] == 4 * m and np.isinf(out[m, 3])
-    c = rec[:, 0:3].astype(np.float64)
-    r = np.abs(rec[:, 7].astype(np.float64))
-    pos = 0
-    for i in range(m):
-        first, count = int(mrange[i, 0]), int(mrange[i, 1])
-        if link[i] & LEAF:
-            cnt = ((int(link[i]) >> 24) & 3) + 1
-            assert 1 <= cnt <= group and (int(link[i]) & 0xFFFFFF) == first == pos and count == cnt     # leaves in member order
-            pos += cnt
-            if cnt == 1:
-                assert not out[i].any()                                          # filled on the device from the filter record
-                continue
-        else:
-            end = int(link[i]) // 4
-            assert i + 1 < end <= m
-            # the members of an inner node are those of the leaves of its subtree: one contiguous range
-            leaves = [j for j in range(i + 1, end) if link[j] & LEAF]
-            assert first == int(mrange[leaves[0], 0]) and count == sum(int(mrange[j, 1]) for j in leaves) and count > group
-        ids = members[first:first + count]
-        C = out[i, 0:3].astype(np.float64) / S
-        k = float(out[i, 3]) / (S * S)
-        c2 = float(C @ C)
-        need = (np.linalg.norm(c[ids] - C, axis=1) + r[ids]).max()
-        round_k = 2.0 ** -23 * max(c2, need * need)
-        assert k <= c2 * (1.0 - EPS) - (1.04 * need) ** 2 * (1.0 + KAPPA) + round_k          # contains its members with the proof's slack
-        assert k >= c2 * (1.0 - EPS) - (1.05 * need) ** 2 * (1.0 + KAPPA) - round_k - 1e-12
-    assert pos == n
-    if n >= 1024 and group == 4:
-        _, _, _, m1 = build(synthetic_spheres(n, seed))
-        assert m < 0.55 * m1                                                     # about half the nodes of one sphere per leaf
