@@ -879,7 +879,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             for (rt_ctx::DevBuf* b : {&c->d_tile_cost[order_set], &c->d_tile_order[order_set]}) {
                 (void)hipFree(b->p);
                 b->p = nullptr; b->cap = 0;
-                RT_HIP(hipMalloc(&b->p, (size_t)order_n * 4u + 4u));       // the list carries a header word
+                RT_HIP(hipMalloc(&b->p, (size_t)order_n * 4u + 8u));       // the list carries two header words
                 b->cap = (size_t)order_n * 4u;
             }
             RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));   // tiles ADD their times

@@ -640,8 +640,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_tiles(const RtFrameArgs A
     const Scene sc = unpack_scene(A);
     const uint32_t groups_x = (A.W + 7u) / 8u;
     const uint32_t n_tiles = groups_x * A.n_local_tiles;
-    const uint32_t split = T.tile_order ? T.tile_order[0] : 0u;
-    const uint32_t n_items = n_tiles + 3u * split;                  // a split tile is four items, one 4x4 quarter each
+    const uint32_t s4 = T.tile_order ? T.tile_order[0] : 0u, s16 = T.tile_order ? T.tile_order[1] : 0u;
+    const uint32_t n_items = n_tiles + 3u * s4 + 15u * s16;         // a split tile is four quarter items or sixteen 2x2 items (order_tiles)
     uint32_t nrays = 0;
     // Items come from the frame's cursor in chunks: every wave starts with the item of its own number (no atomic), then
     // reserves remaining / (4 x waves of the grid) items at a time, at least one, at most sixteen -- atomics on ONE address
@@ -660,17 +660,21 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_tiles(const RtFrameArgs A
         }
         if (item >= n_items) break;
         const uint64_t clk0 = wall_clock64();
-        uint32_t tile = item, part = 4u;                            // part 0-3: a 4x4 quarter; 4: the whole tile
+        uint32_t tile = item, part = 4u;                            // part 0-3: a 4x4 quarter; 4: the whole tile; 16-31: a 2x2 sixteenth
         if (T.tile_order) {
-            if (item < 4u * split) { tile = T.tile_order[1u + (item >> 2)]; part = item & 3u; }
-            else tile = T.tile_order[1u + item - 3u * split];
+            const uint32_t* list = T.tile_order + 2;
+            uint32_t i = item;
+            if (i < 16u * s16) { tile = list[i >> 4]; part = 16u + (i & 15u); }
+            else if ((i -= 16u * s16) < 4u * s4) { tile = list[s16 + (i >> 2)]; part = i & 3u; }
+            else tile = list[s16 + s4 + (i - 4u * s4)];
         }
         const uint32_t by = tile / groups_x, bx = tile - by * groups_x;
-        const uint32_t px = part == 4u ? (lane & 7u) : 4u * (part & 1u) + (lane & 3u);
-        const uint32_t row = part == 4u ? (lane >> 3) : 4u * (part >> 1) + (lane >> 2);
+        uint32_t px = lane & 7u, row = lane >> 3;
+        if (part < 4u) { px = 4u * (part & 1u) + (lane & 3u); row = 4u * (part >> 1) + (lane >> 2); }
+        else if (part >= 16u) { px = 2u * (part & 3u) + (lane & 1u); row = 2u * ((part >> 2) & 3u) + (lane >> 1); }
         const uint32_t x = bx * 8u + px;
         const uint32_t y = (A.tile_first + by * A.tile_step) * 8u + row;
-        if ((part == 4u || lane < 16u) && x < A.W && y < A.H) {
+        if ((part == 4u || (part < 4u && lane < 16u) || (part >= 16u && lane < 4u)) && x < A.W && y < A.H) {
             float dist = 0.0f;
             v3 color = V(1.0f, 1.0f, 1.0f);
             v3 ro = sc.cameraPos, rd = primary_dir(A, sc, x, y);

@@ -19,6 +19,8 @@
 // the winning triangle, its barycentrics and its BLAS, so deferring them is bit-exact).
 // Out-of-range indices follow the robustness rule the oracle fixes (clamp to the last element).
 #include <type_traits>
+#include <cstdlib>
+#include <algorithm>
 
 #include "rt_device.h"
 #include "rt_tri_types.h"
@@ -47,20 +49,26 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     const uint64_t clk0 = wall_clock64();
     const uint32_t groups_x = (A.W + 8u * WAVES - 1u) / (8u * WAVES);
     const uint32_t n_tiles = groups_x * A.n_local_tiles;
-    uint32_t tile = blockIdx.x, part = 4u;                                  // part 0-3: a 4x4 quarter; 4: the whole tile
+    // part 0-3: a 4x4 quarter; 4: the whole tile; 16-31: a 2x2 sixteenth (the very longest tiles: four lanes diverge least, and
+    // a frame on its own has idle wave slots to spare)
+    uint32_t tile = blockIdx.x, part = 4u;
     if (T.tile_order) {
-        const uint32_t split = T.tile_order[0];
-        if (blockIdx.x < 4u * split) { tile = T.tile_order[1u + (blockIdx.x >> 2)]; part = blockIdx.x & 3u; }
-        else if (blockIdx.x - 3u * split < n_tiles) tile = T.tile_order[1u + blockIdx.x - 3u * split];
-        else return;                                                        // the grid is sized for the most quarters there can be
+        const uint32_t s4 = T.tile_order[0], s16 = T.tile_order[1];
+        const uint32_t* list = T.tile_order + 2;
+        uint32_t i = blockIdx.x;
+        if (i < 16u * s16) { tile = list[i >> 4]; part = 16u + (i & 15u); }
+        else if ((i -= 16u * s16) < 4u * s4) { tile = list[s16 + (i >> 2)]; part = i & 3u; }
+        else if ((i -= 4u * s4) < n_tiles - s16 - s4) tile = list[s16 + s4 + i];
+        else return;                                                        // the grid is sized for the most parts there can be
     }
     const uint32_t by = tile / groups_x, bx = tile - by * groups_x;
-    if (part != 4u && lane >= 16u) return;
-    const uint32_t px = part == 4u ? (lane & 7u) : 4u * (part & 1u) + (lane & 3u);
-    const uint32_t row = part == 4u ? (lane >> 3) : 4u * (part >> 1) + (lane >> 2);
+    if ((part < 4u && lane >= 16u) || (part >= 16u && lane >= 4u)) return;
+    uint32_t px = lane & 7u, row = lane >> 3;
+    if (part < 4u) { px = 4u * (part & 1u) + (lane & 3u); row = 4u * (part >> 1) + (lane >> 2); }
+    else if (part >= 16u) { px = 2u * (part & 3u) + (lane & 1u); row = 2u * ((part >> 2) & 3u) + (lane >> 1); }
     const uint32_t x = bx * (8u * WAVES) + wave * 8u + px;
     const uint32_t y = (A.tile_first + by * A.tile_step) * 8u + row;
-    if (x >= A.W || y >= A.H) return;          // thread 0 leaves here only with its whole tile or quarter: its pixel is their first
+    if (x >= A.W || y >= A.H) return;          // thread 0 leaves here only with its whole tile or part: its pixel is their first
 
     const Scene sc = unpack_scene(A);
     uint32_t nrays = 0;
@@ -118,10 +126,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
 //   * one workgroup turns the costs into the NEXT frame's work list on the same stream: tiles longest first (a counting sort
 //     over quarter-octave classes), and the tiles longer than half the frame's throughput time -- sum of all costs / wave
 //     slots / 2 --, at most one in sixteen and 1024 (a quarter-wave for every wave slot of the chip), as four 4x4 quarters each: a quarter of the lanes diverge a quarter as much, and
-//     the frame's longest wave shrinks accordingly.  order[0] = number of split tiles, order[1...] = the permutation.
+//     the frame's longest wave shrinks accordingly; round 4: the tiles longer than FOUR times the throughput time, at most one in 64
+//     and 256, as sixteen 2x2 blocks (four lanes each) -- a frame on its own leaves the wave slots for them idle anyway.
+//     order[0] = tiles in quarters, order[1] = tiles in sixteenths (the head of the list), order[2...] = the permutation.
 // The picture does not depend on any of it: a pixel is rendered by the same code whatever its turn and company; any
 // array of costs yields a permutation and a split count within the grid's bound.
-__global__ __launch_bounds__(1024) void order_tiles(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, uint32_t wave_slots) {
+__global__ __launch_bounds__(1024) void order_tiles(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, uint32_t wave_slots,
+                                                    uint32_t mult16, uint32_t cap16) {
     __shared__ uint32_t bin[128];
     __shared__ unsigned long long total;
     if (threadIdx.x < 128u) bin[threadIdx.x] = 0u;
@@ -138,24 +149,30 @@ __global__ __launch_bounds__(1024) void order_tiles(uint32_t* __restrict__ cost,
     __syncthreads();
     if (threadIdx.x == 0u) {                       // exclusive prefix over the classes, longest class first
         const unsigned long long thr = total / (2ull * (wave_slots ? wave_slots : 1u));
-        const uint32_t kt = cls(thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr);
-        const unsigned long long whole = 4ull * thr;           // twice the throughput time
-        const uint32_t kw = cls(whole > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)whole);
-        uint32_t acc = 0u, split = 0u;
+        auto cls_of = [&](unsigned long long v) { return cls(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v); };
+        const uint32_t kt = cls_of(thr);
+        const uint32_t kw = cls_of(4ull * thr);           // twice the throughput time
+        const uint32_t k16 = cls_of((unsigned long long)mult16 * thr);          // mult16 / 2 times the throughput time: as sixteenths
+        uint32_t acc = 0u, split = 0u, split16 = 0u;
         bool pays = false;                         // some tile takes more than twice the throughput time: the frame waits for it.
         for (int k = 127; k >= 0; --k) {           // (Otherwise quarters only add waves: 4K, 0.77 -> 0.81 ms with them.)
             const uint32_t v = bin[k];
             bin[k] = acc; acc += v;
             if (k > (int)kt) split = acc;          // tiles of the classes above the threshold's: all longer than it
+            if (k > (int)k16) split16 = acc;
             if (k > (int)kw && v) pays = true;
         }
-        if (!pays) split = 0u;
-        const uint32_t most = n / 16u < 1024u ? n / 16u : 1024u;      // rt_tri_max_split
-        order[0] = split < most ? split : most;
+        if (!pays) split = split16 = 0u;
+        const uint32_t most = n / 16u < 1024u ? n / 16u : 1024u, most16 = n / 64u < cap16 ? n / 64u : cap16;      // rt_tri_grid
+        if (split16 > most16) split16 = most16;
+        if (split > most) split = most;
+        if (split < split16) split = split16;
+        order[0] = split - split16;                // tiles rendered as four quarters ...
+        order[1] = split16;                        // ... behind the tiles rendered as sixteen 2x2 blocks: the head of the list
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
-        order[1u + atomicAdd(&bin[cls(cost[i])], 1u)] = i;
+        order[2u + atomicAdd(&bin[cls(cost[i])], 1u)] = i;
         cost[i] = 0u;                              // the next frame adds its times up from zero
     }
 }
@@ -222,7 +239,7 @@ template <typename STK, int OCC, bool PACKED, int WAVES = 1>
 static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
     const dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
     const uint32_t n_tiles = grid.x * grid.y;       // trace_triangles decodes the tile itself; with a work list: room for the quarters
-    const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) : n_tiles, 1, 1);   // order_tiles: at most that many tiles in quarters
+    const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) + 15u * std::min(n_tiles / 64u, 256u) : n_tiles, 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
     if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK, PACKED>), grid, dim3(64 * WAVES), 0, s, a, t);
     else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED>), line, dim3(64 * WAVES), 0, s, a, t);
     else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED>), line, dim3(64 * WAVES), 0, s, a, t);
@@ -230,7 +247,12 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, h
 
 hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtk::order_tiles, dim3(1), dim3(1024), 0, s, cost, order, n_tiles, wave_slots);
+    uint32_t mult16 = 8u, cap16 = 256u;             // sixteenths from four times the throughput time on, at most 256 tiles (launch_tri sizes the grid for them)
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_MULT16")) mult16 = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT355_TRI_CAP16")) cap16 = std::min(256u, (uint32_t)atoi(e));
+#endif
+    hipLaunchKernelGGL(rtk::order_tiles, dim3(1), dim3(1024), 0, s, cost, order, n_tiles, wave_slots, mult16, cap16);
     return hipGetLastError();
 }
 

@@ -11,9 +11,10 @@ make -s lib
 /opt/rocm/bin/hipcc $FL -DRT355_DEV_EXPORTS -DRT355_BUILD_ID='"dev"' -c $CS/rt_api.hip -o /tmp/rtdev/rt_api.o &
 /opt/rocm/bin/hipcc $FL -fno-slp-vectorize -DRT_BVH_DEV_ENV -c $CS/rt_bvh.hip -o /tmp/rtdev/rt_bvh.o &
 /opt/rocm/bin/hipcc $FL -fno-slp-vectorize -DRT_FLOW_COUNT -c $CS/rt_flow.hip -o /tmp/rtdev/rt_flow_count.o &
+/opt/rocm/bin/hipcc $FL -fno-slp-vectorize -DRT_TRI_DEV_ENV -c $CS/rt_triangles.hip -o /tmp/rtdev/rt_triangles.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/bin/librt355_dev.so /tmp/rtdev/rt_api.o /tmp/rtdev/rt_bvh.o \
-    $CS/rt_kernels.o $CS/rt_triangles.o $CS/rt_flow.o $CS/rt_assemble.o $CS/rt_comm.o -L/opt/rocm/lib -lrccl
+    $CS/rt_kernels.o /tmp/rtdev/rt_triangles.o $CS/rt_flow.o $CS/rt_assemble.o $CS/rt_comm.o -L/opt/rocm/lib -lrccl
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/bin/librt355_fc.so /tmp/rtdev/rt_api.o /tmp/rtdev/rt_bvh.o \
     $CS/rt_kernels.o $CS/rt_triangles.o /tmp/rtdev/rt_flow_count.o $CS/rt_assemble.o $CS/rt_comm.o -L/opt/rocm/lib -lrccl
 ls -la tools/bin/*.so
