@@ -126,8 +126,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
 //   * one workgroup turns the costs into the NEXT frame's work list on the same stream: tiles longest first (a counting sort
 //     over quarter-octave classes), and the tiles longer than half the frame's throughput time -- sum of all costs / wave
 //     slots / 2 --, at most one in sixteen and 1024 (a quarter-wave for every wave slot of the chip), as four 4x4 quarters each: a quarter of the lanes diverge a quarter as much, and
-//     the frame's longest wave shrinks accordingly; round 4: the tiles longer than FOUR times the throughput time, at most one in 64
-//     and 256, as sixteen 2x2 blocks (four lanes each) -- a frame on its own leaves the wave slots for them idle anyway.
+//     the frame's longest wave shrinks accordingly; round 4: the tiles longer than TWICE the throughput time, at most one in 64
+//     and 64, as sixteen 2x2 blocks (four lanes each) -- a frame on its own leaves the wave slots for them idle anyway.
 //     order[0] = tiles in quarters, order[1] = tiles in sixteenths (the head of the list), order[2...] = the permutation.
 // The picture does not depend on any of it: a pixel is rendered by the same code whatever its turn and company; any
 // array of costs yields a permutation and a split count within the grid's bound.
