@@ -247,7 +247,10 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, h
 
 hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    uint32_t mult16 = 8u, cap16 = 256u;             // sixteenths from four times the throughput time on, at most 256 tiles (launch_tri sizes the grid for them)
+    // Sixteenths from twice the throughput time on, at most 64 tiles (1 / 2 / 4 / 8 times: REF 0.459 / 0.449 / 0.537 / 0.539 ms one at a
+    // time, TRI 0.255 / 0.256 / 0.291 / 0.372; 64 against 256 tiles: REF 0.449 against 0.465; a third level of single pixels
+    // changes nothing: profiles/r04/tri_split_sweep16.log, tri_split_sweep64.log).  launch_tri sizes the grid for 256.
+    uint32_t mult16 = 4u, cap16 = 64u;
 #ifdef RT_TRI_DEV_ENV
     if (const char* e = getenv("RT355_TRI_MULT16")) mult16 = (uint32_t)atoi(e);
     if (const char* e = getenv("RT355_TRI_CAP16")) cap16 = std::min(256u, (uint32_t)atoi(e));
