@@ -696,7 +696,9 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     bool use_flow = false;
     RtFlowArgs fl;
     std::memset(&fl, 0, sizeof fl);
-    if (tri && c->kernel != RT_KERNEL_HEATMAP && (c->variant == 7 || c->variant == 8)) {
+    bool have_pairs = false;       // the relinked copy is current and covers this frame's roots (also read by the default kernel)
+    const bool persistent = c->variant == 7 || c->variant == 8;
+    if (tri && c->kernel != RT_KERNEL_HEATMAP && c->variant != 6) {
         const uint32_t n_nodes = (uint32_t)(c->nodes_used / 32u);
         const uint32_t n_inst = (uint32_t)(c->inst.blas.size() / 20u);
         const bool fits = c->inst.blas_on && c->inst.lookup_on && n_inst >= 1u && n_inst <= kFlowInst && !c->inst.lookup.empty() &&
@@ -715,7 +717,14 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
                     if (rc != RT_OK) return rc;
                 }
             }
-            if (c->flow.ok) {
+            have_pairs = c->flow.ok && c->flow.n_pairs != 0u;
+            if (have_pairs) {
+                fl.n_pairs = c->flow.n_pairs;
+                const uint32_t last = n_nodes - 1u;
+                for (uint32_t i = 0; i < n_inst; ++i)
+                    fl.root_meta[i] = rt_flow_meta(c->h_nodes.data(), n_nodes, roots[i] < last ? roots[i] : last, c->flow.pair_of);
+            }
+            if (c->flow.ok && persistent) {
                 for (int k = 0; k < kStreams; ++k)
                     if (!c->d_flow_ovf[k].p) {
                         const size_t bytes = (size_t)c->n_cus * 16u * kFlowOvfWords * 4u;
@@ -905,6 +914,8 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
         ts.tile_order = nullptr; ts.tile_cost = nullptr;
+        ts.pairs = (have_pairs && ts.n_blas <= 12u) ? static_cast<const float4*>(c->d_flow.p) : nullptr;
+        for (uint32_t i = 0; i < 12u; ++i) ts.root_meta[i] = fl.root_meta[i];
 #ifdef RT355_DEV_EXPORTS
         if (order_set >= 0 && getenv("RT355_KEEP_TILE_COST")) RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));
 #endif

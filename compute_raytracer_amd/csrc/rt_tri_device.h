@@ -53,8 +53,13 @@ __device__ __forceinline__ TriLds stage_head(const RtTriScene& T, float4* s_node
     // (the last padding word of staged record k carries entry k of the BLAS lookup table, RK:223: one dependent global load
     // less per instance and ray)
     L.n_lookup = T.n_blas_lookup < L.n_blas ? T.n_blas_lookup : L.n_blas;
-    for (uint32_t i = threadIdx.x; i < 20u * L.n_blas; i += 64 * WAVES)
-        s_blas[i] = (i % 20u == 19u && i / 20u < L.n_lookup) ? T.blas_lookup[i / 20u] : T.blas[i];
+    // (with the relinked pair records, T.pairs: the padding word before it carries the root's (count, left) meta -- the root
+    // node itself is then never loaded)
+    for (uint32_t i = threadIdx.x; i < 20u * L.n_blas; i += 64 * WAVES) {
+        float v = (i % 20u == 19u && i / 20u < L.n_lookup) ? T.blas_lookup[i / 20u] : T.blas[i];
+        if (T.pairs && i % 20u == 17u) v = __uint_as_float(T.root_meta[i / 20u]);
+        s_blas[i] = v;
+    }
     __syncthreads();
     L.nodes = s_nodes; L.blas = s_blas;
     return L;
@@ -122,7 +127,10 @@ __device__ __forceinline__ bool hit_triangle(const RtTriScene& T, uint32_t slot,
 // result was in registers at push time.  The packed stack keeps (count << 16 | left) of the pushed child instead, in the
 // same slot under the same clamping: a pop is one LDS read.  Valid while every count, child index and lookup slot fits 16
 // bits, which the host checks when the buffers are written (rt_api.hip: packed_ok).
-template <bool COUNT, typename STK, bool PACKED>
+// PAIRS (with PACKED, and every instance staged): the walk reads the library's relinked pair records (rt_flow_build.h) -- one
+// 64-byte record per inner node, metas packed when the copy was built: no u32(f32) per node, no packing at a push, and the
+// root's meta comes with the staged instance record instead of a node load.  Same boxes, same order, same decisions.
+template <bool COUNT, typename STK, bool PACKED, bool PAIRS = false>
 __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L, uint32_t bi, v3 o, v3 d, float& nearest,
                                            TriHit& hit, typename std::conditional<PACKED, uint32_t, STK>::type* stack,
                                            uint32_t stride, float& traces) {
@@ -142,6 +150,54 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
                     ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.0f,
                     ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.0f);       // RK:255
     const v3 inv = V(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);        // RK:396
+    if (PAIRS) {
+        uint32_t pnode = __float_as_uint(L.blas[20u * bi + 17u]);   // RK:265: the root's (count, left), relinked
+        uint32_t psp = 0;                                           // RK:267
+        float pNearest = nearest;                                   // RK:269
+        for (;;) {                                                  // RK:271
+            const uint32_t count = pnode >> 16, left = pnode & 0xFFFFu;   // RK:272-273
+            if (count == 0u) {                                      // RK:275
+                if (COUNT) traces += 2.0f;                          // HK:242
+                const float4* g = T.pairs + 4u * (size_t)left;
+                const float4 q0 = g[0], q1 = g[1], q2 = g[2], q3 = g[3];
+                NodeR c1, c2;
+                c1.lo = V(q0.x, q0.y, q0.z); c1.hi = V(q1.x, q1.y, q1.z);
+                c2.lo = V(q2.x, q2.y, q2.z); c2.hi = V(q3.x, q3.y, q3.z);
+                const uint32_t m1 = __float_as_uint(q0.w), m2 = __float_as_uint(q2.w);
+                float d1 = hit_aabb(oo, inv, c1);                   // RK:279
+                float d2 = hit_aabb(oo, inv, c2);                   // RK:280
+                const bool swap = d1 > d2;                          // RK:283-290
+                if (swap) { const float tmp = d1; d1 = d2; d2 = tmp; }
+                if (d1 > pNearest) {                                // RK:292
+                    if (psp == 0u) break;
+                    psp -= 1u;
+                    pnode = stack[sclamp(psp) * stride];            // RK:297-298
+                } else {
+                    pnode = swap ? m2 : m1;                         // RK:302
+                    if (d2 < pNearest) {                            // RK:303-304 (no overflow guard upstream)
+                        stack[sclamp(psp) * stride] = swap ? m1 : m2;
+                        psp += 1u;
+                    }
+                }
+            } else {
+                for (uint32_t i = 0; i < count; ++i) {              // RK:311
+                    uint32_t li = i + left;
+                    if (li >= T.n_tri_lookup) li = T.n_tri_lookup - 1u;
+                    if (COUNT) traces += 1.0f;                      // HK:279
+                    float t, u, v;
+                    if (hit_triangle(T, li, oo, od, pNearest, t, u, v)) {   // RK:312-321
+                        pNearest = t;
+                        hit.t = t; hit.u = u; hit.v = v; hit.tri = (int)li; hit.blas = (int)bi;
+                    }
+                }
+                if (psp == 0u) break;                               // RK:324
+                psp -= 1u;
+                pnode = stack[sclamp(psp) * stride];                // RK:328-329
+            }
+        }
+        nearest = pNearest < nearest ? pNearest : nearest;          // RK:227-229
+        return;
+    }
     NodeR node = load_node(T, u32f(m[16]));                         // RK:265
     uint32_t sp = 0;                                                // RK:267
     float blasNearest = nearest;                                    // RK:269
@@ -199,7 +255,7 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
 }
 
 // RK:168-244 traceTLAS.  tstack / bstack: this lane's two LDS stacks.
-template <bool COUNT, typename STK, bool PACKED>
+template <bool COUNT, typename STK, bool PACKED, bool PAIRS = false>
 __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& L, v3 o, v3 d, STK* tstack,
                                              typename std::conditional<PACKED, uint32_t, STK>::type* bstack, uint32_t stride, float& traces) {
     TriHit hit; hit.t = 0.0f; hit.u = hit.v = 0.0f; hit.tri = -1; hit.blas = -1;   // RK:170-171
@@ -237,7 +293,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
                 if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
                 uint32_t bi = u32f(li < L.n_lookup ? L.blas[20u * li + 19u] : T.blas_lookup[li]);   // RK:223
                 if (bi >= T.n_blas) bi = T.n_blas - 1u;
-                trace_blas<COUNT, STK, PACKED>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
+                trace_blas<COUNT, STK, PACKED, PAIRS>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
             }
             if (sp == 0u) break;                                    // RK:233
             sp -= 1u;

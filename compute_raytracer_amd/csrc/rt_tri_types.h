@@ -15,6 +15,10 @@ struct RtTriScene {
     // Work list (rt_triangles.hip: order_tiles): tile_order[0] tiles are rendered as four quarters, tile_order[1...] is the
     // order of the tiles (null: every tile whole, in index order); every workgroup adds the time it took to
     // tile_cost[tile] (null: nowhere), from which the list of the next frame on this stream is made.
+    // Relinked copy of the BLAS trees (rt_flow_build.h), when the scene fits it (rt_api.hip: flow_ok; null otherwise): the two
+    // children of an inner node as one 64-byte record with packed (count << 16 | x) metas, and per instance the root's meta.
+    const float4* pairs;
+    uint32_t root_meta[12];    // instances the tile kernel stages (rt_tri_device.h: kLdsBlas)
     const uint32_t* tile_order;
     uint32_t* tile_cost;
 };

@@ -181,10 +181,11 @@ int rt_set_mode(rt_ctx* ctx, int mode);
  * 0 = bounding-sphere hierarchy from 128 spheres on (from 72 on once the caller keeps frames in flight), single
  * brute-force kernel below;
  * 4 = hierarchy for any sphere count; 5 = brute force (two-kernel pipeline from 320 spheres on);
- * 1, 2, 3 = individual brute-force forms.  Triangle scenes: 0 (and 6) = one workgroup per tile (rt_triangles.hip);
- * 7 / 8 = the persistent kernels of rt_flow.hip -- the step machine trace_flow / the tile loop trace_tiles -- for scenes of up
- * to 16 instances whose node buffer and lookup table fit 16-bit indices (others fall back to 0): measured slower than the
- * default, kept selectable.  Every variant produces the same pixels.  See DESIGN.md. */
+ * 1, 2, 3 = individual brute-force forms.  Triangle scenes: 0 = one workgroup per tile (rt_triangles.hip), reading the BLAS
+ * trees from the library's relinked pair records where the scene fits them (up to 12 instances, node buffer and lookup table
+ * within 16-bit indices); 6 = the same kernel on the reference's node buffer only; 7 / 8 = the persistent kernels of rt_flow.hip
+ * -- the step machine trace_flow / the tile loop trace_tiles -- for scenes of up to 16 instances (others fall back to 0):
+ * measured slower than the default, kept selectable.  Every variant produces the same pixels.  See DESIGN.md. */
 int rt_set_variant(rt_ctx* ctx, int variant);
 
 /* ---- multi-GPU partition --------------------------------------------------------------- */

@@ -22,12 +22,13 @@ def random_sky(seed, w=8, h=8):
     return m
 
 
-# the kernels of the triangle path: 0 = the library's choice, one workgroup per tile (rt_triangles.hip); 7 = the step machine,
-# 8 = the persistent tile loop (rt_flow.hip: trace_flow / trace_tiles; these scenes fit them)
-KERNELS = {0: "triangles", 7: "triangles_flow", 8: "triangles_tiles"}
+# the kernels of the triangle path: 0 = the library's choice, one workgroup per tile over the relinked pair records
+# (rt_triangles.hip, PAIRS), 6 = the same kernel over the reference's node buffer; 7 = the step machine, 8 = the persistent tile
+# loop (rt_flow.hip: trace_flow / trace_tiles; these scenes fit all of them)
+KERNELS = {0: "triangles", 6: "triangles", 7: "triangles_flow", 8: "triangles_tiles"}
 
 
-@pytest.mark.parametrize("variant", [0, 7, 8])
+@pytest.mark.parametrize("variant", [0, 6, 7, 8])
 @pytest.mark.parametrize("seed,W,H,B", [(1, 320, 200, 4), (2, 333, 207, 2), (3, 64, 64, 8), (4, 8, 8, 1), (5, 200, 120, 0)])
 def test_triangle_scene_bit_exact(oracle, seed, W, H, B, variant):
     scene, mat = triangle_scene(seed=seed, n_models=3)
@@ -290,7 +291,7 @@ def spine_scene(depth):
     return rt.SceneRaytracing.from_packed(d)
 
 
-@pytest.mark.parametrize("variant", [0, 7, 8])
+@pytest.mark.parametrize("variant", [0, 6, 7, 8])
 @pytest.mark.parametrize("depth", [7, 12, 19, 20, 21, 33])
 def test_stack_depth_beyond_the_lds_slots_and_beyond_the_reference_stack(oracle, depth, variant):
     scene = spine_scene(depth)
