@@ -1,5 +1,8 @@
 """One-off differential run (development): random procedural triangle scenes through trace_triangles and the
 heatmap kernel against the CPU oracle -- instance counts, tessellations, cameras, skies, bounce limits, frame sizes.
+Round 4: every scene through all four ray-trace variants (0: one workgroup per tile over the relinked pair records, 6: over
+the node buffer, 7: the step machine, 8: the persistent tile loop), frames one at a time and -- every fifth scene -- four
+frames in flight with the instances moving.
 usage: python tools/diff_run_tri.py [scenes=120] [first seed=7000]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,10 +30,26 @@ for seed in range(first, first + count):
     W, H, B = int(rng.integers(24, 200)), int(rng.integers(16, 130)), int(rng.choice([0, 1, 2, 4, 6]))
     bufs = tri_buffers(scene, mat)
     ref, _, rays = oracle.render_tri(scene.pack_params(B), bufs, sky.faces, W, H)
-    img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky)
+    ok = True
+    for variant in (0, 6, 7, 8):
+        img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky, variant=variant)
+        ok = ok and np.array_equal(img, ref) and st["rays"] == rays
     href, _ = oracle.heatmap_tri(scene.pack_params(B), bufs, W, H)
     himg, _ = gpu_render_tri(scene, mat, W, H, B, skybox=sky, heatmap=True)
-    ok = np.array_equal(img, ref) and st["rays"] == rays and np.array_equal(himg, href)
+    ok = ok and np.array_equal(himg, href)
+    if (seed - first) % 5 == 4:                       # frames in flight, instances moving, each against the oracle
+        for variant in (0, 7, 8):
+            r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+            r.set_variant(variant)
+            host, want = r.host_frames(4), []
+            for f in range(4):
+                scene.update(0.17)
+                r.recalculateScene(); r.enqueue()
+                r.read_pixels_async(0, host[f])
+                want.append(oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)[0])
+            r.wait(); r.read_pixels_wait()
+            ok = ok and all(np.array_equal(host[f].reshape(H, W, 4), want[f]) for f in range(4))
+            r.close()
     rays_total += rays
     if not ok:
         bad += 1
