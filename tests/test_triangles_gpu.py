@@ -126,10 +126,12 @@ def test_incomplete_triangle_scene_is_a_state_error():
         L.rt_destroy(ctx)
 
 
-def test_instance_updates_travel_with_the_frame(oracle):
+@pytest.mark.parametrize("n_streams", [2, 3])
+def test_instance_updates_travel_with_the_frame(oracle, n_streams):
     """RR:169-192 rewrites BLAS records, BLAS lookup and TLAS nodes before every frame.  Those writes no longer
     drain: frames are enqueued back to back (rt_render_to, nothing waited for in between) while the host keeps
-    rewriting the instance data; every frame must show the state it was enqueued with."""
+    rewriting the instance data; every frame must show the state it was enqueued with.  (Three host streams: a rotation
+    whose period does not divide the four versions of the instance buffers -- the ordering must not lean on it)"""
     import torch
     scene, mat = triangle_scene(seed=21, n_models=3)
     sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
@@ -139,14 +141,14 @@ def test_instance_updates_travel_with_the_frame(oracle):
         r.render()                                                    # static part uploaded, first state applied
         base = r.stats()["instance_uploads"]
         bufs = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(N)]
-        streams = [torch.cuda.Stream() for _ in range(2)]
+        streams = [torch.cuda.Stream() for _ in range(n_streams)]
         torch.cuda.synchronize()
         refs = []
         for f in range(N):
             scene.update(0.21)
             scene.camera.move(0.05, -0.02)
             refs.append(oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)[0])
-            r.render_to(bufs[f].data_ptr(), bufs[f].numel(), streams[f % 2].cuda_stream)      # no wait
+            r.render_to(bufs[f].data_ptr(), bufs[f].numel(), streams[f % n_streams].cuda_stream)      # no wait
         r.wait()
         torch.cuda.synchronize()
         st = r.stats()
