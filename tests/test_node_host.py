@@ -307,3 +307,19 @@ const s=require('./node/scene-raytracing'); const {RendererRaytracing}=require('
         scene.camera.move(0.07, -0.03)
         want.append(hashlib.sha256(oracle.render(scene.pack_params(B), scene.pack_spheres(), sky.faces, W, H)[0].tobytes()).hexdigest())
     assert got["sha"] == want and got["kernel"] == "bvh_pixels<8>" and len(got["build"]) == 16
+
+
+@pytest.mark.gpu
+def test_animation_loop_bench_in_node():
+    """tools/node_loop_bench.py: the reference's animation loop (scene.update, camera.move, await render) in the reference's
+    host language against the static loop -- a few frames at a small size: the script runs, reports both, and the JS scene
+    update is a small part of a frame."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "node_loop_bench.py"), "6", "320", "200"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["triangles"] == 12846 and d["frames"] == 6 and d["rays"] > 320 * 200
+    assert 0 < d["staticLoopMsPerFrame"] < 50 and 0 < d["animatedLoopMsPerFrame"] < 50
+    assert d["hostSceneUpdateMsPerFrame"] < 0.5
