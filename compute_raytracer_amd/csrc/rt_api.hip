@@ -736,6 +736,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
                 fl.pairs = static_cast<const float4*>(c->d_flow.p);
                 fl.n_pairs = c->flow.n_pairs;
                 fl.thresh = 24u;
+                fl.static_pct = 75u;
                 const uint32_t last = n_nodes - 1u;
                 for (uint32_t i = 0; i < n_inst; ++i)
                     fl.root_meta[i] = rt_flow_meta(c->h_nodes.data(), n_nodes, roots[i] < last ? roots[i] : last, c->flow.pair_of);
@@ -933,6 +934,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             if (const char* e = getenv("RT355_FLOW_BLOCKS")) blocks = (uint32_t)atoi(e);
             if (const char* e = getenv("RT355_FLOW_THRESH")) fl.thresh = (uint32_t)atoi(e);
             if (const char* e = getenv("RT355_FLOW_LDSPAIRS")) fl.lds_pairs_cap = (uint32_t)atoi(e) + 1u;
+            if (const char* e = getenv("RT355_FLOW_STATIC")) fl.static_pct = std::min(100u, (uint32_t)atoi(e));
             if (waves != 16u && waves != 8u && waves != 4u) waves = 16u;
             if (per_cu < 1u) per_cu = 1u;
             if (blocks * waves > c->n_cus * 16u) blocks = c->n_cus * 16u / waves;      // the overflow area is sized for that many waves

@@ -643,20 +643,29 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_tiles(const RtFrameArgs A
     const uint32_t s4 = T.tile_order ? T.tile_order[0] : 0u, s16 = T.tile_order ? T.tile_order[1] : 0u;
     const uint32_t n_items = n_tiles + 3u * s4 + 15u * s16;         // a split tile is four quarter items or sixteen 2x2 items (order_tiles)
     uint32_t nrays = 0;
-    // Items come from the frame's cursor in chunks: every wave starts with the item of its own number (no atomic), then
-    // reserves remaining / (4 x waves of the grid) items at a time, at least one, at most sixteen -- atomics on ONE address
-    // complete about 12 ns apart, and a 4K frame has 129,600 tiles: one atomic per tile would be a 1.6 ms floor under the frame.
+    // Items.  Atomics on ONE address complete about 12 ns apart: one per tile is a 0.2 ms floor under a 17,800-tile frame and 1.6 ms
+    // under a 4K frame, and 4,096 waves asking at once queue behind each other.  So a wave takes the first part of its share
+    // WITHOUT asking: items w, w + G, w + 2G ... (G waves in the grid) of the work list -- longest first, so the strided shares
+    // are about equal --, F.static_pct per cent of the list; only the rest goes through the frame's cursor, in chunks.
     const uint32_t grid_waves = gridDim.x * (uint32_t)WAVES;
-    uint32_t item = blockIdx.x * (uint32_t)WAVES + wave, item_end = item + 1u;
-    for (;; ++item) {
-        if (item == item_end) {
-            const uint32_t seen = item < grid_waves ? grid_waves : item;          // a lower bound of the cursor
-            uint32_t want = n_items > seen ? (n_items - seen) / (4u * grid_waves) : 0u;
-            want = want < 1u ? 1u : (want > 16u ? 16u : want);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&A.qctrl[2], want);
-            base = __builtin_amdgcn_readfirstlane(base) + grid_waves;
-            item = base; item_end = base + want;
+    const uint32_t wave_id = blockIdx.x * (uint32_t)WAVES + wave;
+    const uint32_t rounds = (uint32_t)(((unsigned long long)(n_items / grid_waves) * F.static_pct) / 100ull);   // static rounds of G items
+    const uint32_t dyn0 = rounds * grid_waves;                      // the cursor hands out items [dyn0, n_items)
+    uint32_t k = 0, item = wave_id, item_end = 0;                   // k < rounds: static item wave_id + k G
+    for (;;) {
+        if (k < rounds) { item = wave_id + k * grid_waves; ++k; }
+        else {
+            if (item_end == 0u || item + 1u >= item_end) {
+                const uint32_t seen = item_end ? item_end : dyn0;   // a lower bound of the cursor
+                uint32_t want = n_items > seen ? (n_items - seen) / (4u * grid_waves) : 0u;
+                want = want < 1u ? 1u : (want > 16u ? 16u : want);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&A.qctrl[2], want);
+                base = __builtin_amdgcn_readfirstlane(base) + dyn0;
+                item = base; item_end = base + want;
+            } else {
+                ++item;
+            }
         }
         if (item >= n_items) break;
         const uint64_t clk0 = wall_clock64();

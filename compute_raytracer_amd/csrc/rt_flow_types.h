@@ -15,6 +15,7 @@ struct RtFlowArgs {
     uint32_t root_meta[kFlowInst];      // per instance: (count << 16 | left) of its root node, inner roots relinked
     uint32_t* ovf;                      // overflow stacks: kFlowOvfWords words per wave of the grid
     uint32_t lds_pairs_cap;             // development knob: at most this many staged records (0: no limit)
+    uint32_t static_pct;                // trace_tiles: this share (0 ... 100) of every wave's items is assigned statically, strided over the work list
 };
 
 size_t rt_flow_lds_bytes(uint32_t waves, uint32_t lds_pairs);
