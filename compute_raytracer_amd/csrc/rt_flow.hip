@@ -114,6 +114,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A,
     uint32_t cur = 0, end = 0;                                   // wave-uniform chunk of the cursor
     uint32_t chunk_ty = 0, chunk_tx = 0, chunk_first = ~0u;
     bool exhausted = false;
+    const uint32_t flow_grid = gridDim.x * (uint32_t)WAVES, flow_wave = blockIdx.x * (uint32_t)WAVES + wave;
+    const uint32_t flow_rounds = (uint32_t)(((unsigned long long)((total >> 6) / flow_grid) * F.static_pct) / 100ull);
+    uint32_t flow_k = 0;
     // the ray every path starts with enters the TLAS at node 0 (RK:175): its (count, left), once per wave
     const uint32_t root_tnode = pack_node(flow_node(T, a_nodes, L.n_nodes, 0u));
 
@@ -404,9 +407,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void trace_flow(const RtFrameArgs A,
             uint64_t idle = __ballot(st == ST_IDLE);
             while (idle && !exhausted) {
                 if (cur == end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&A.qctrl[2], 64u);
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    // the next tile: the first F.static_pct per cent of a wave's tiles are w, w + G, w + 2G ... (G waves in the
+                    // grid) without asking; the rest comes from the frame's cursor (atomics on one address queue: see trace_tiles)
+                    uint32_t base;
+                    if (flow_k < flow_rounds) { base = (flow_wave + flow_k * flow_grid) * 64u; ++flow_k; }
+                    else {
+                        base = 0;
+                        if (lane == 0) base = atomicAdd(&A.qctrl[2], 64u);
+                        base = __builtin_amdgcn_readfirstlane(base) + flow_rounds * flow_grid * 64u;
+                    }
                     if (base >= total) { exhausted = true; break; }
                     cur = base;
                     end = min(base + 64u, total);
