@@ -305,3 +305,28 @@ def test_stack_depth_beyond_the_lds_slots_and_beyond_the_reference_stack(oracle,
     img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky, variant=variant)
     assert np.array_equal(img, ref), diff_stats(img, ref)
     assert st["rays"] == rays and abi.KERNEL_IDS[st["kernel_id"]] == KERNELS[variant]
+
+
+@pytest.mark.parametrize("variant", [0, 7, 8])
+def test_an_instance_that_changes_its_mesh_rebuilds_the_relinked_copy(oracle, variant):
+    """The library's relinked copy of the BLAS trees is built from the roots the instance records name.  The reference rewrites
+    those records before every frame (RR:169-174) and nothing in the interface says a root may not change: a frame that names a
+    root the copy does not know must rebuild it (rt_api.hip: rt_flow_covers) -- here model 0 switches from the coarse sphere to
+    the fine one, which no instance had referenced before, and back."""
+    scene, mat = triangle_scene(seed=33, n_models=1)              # models: [sphere mesh 0, floor (mesh 2)]; mesh 1 unreferenced
+    assert sorted(set(int(k) for k in scene.instances.mesh_index)) == [0, 2]
+    sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
+    W, H, B = 200, 120, 3
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+    r.set_variant(variant)
+    try:
+        for mesh in (0, 1, 0, 1):
+            scene.instances.mesh_index[0] = mesh
+            scene.update(0.1)
+            r.render()
+            ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
+            assert np.array_equal(r.read_pixels(), ref), (mesh, diff_stats(r.read_pixels(), ref))
+            assert r.stats()["rays"] == rays
+            assert abi.KERNEL_IDS[r.stats()["kernel_id"]] == KERNELS[variant]
+    finally:
+        r.close()
