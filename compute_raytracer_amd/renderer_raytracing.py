@@ -132,13 +132,18 @@ class RendererRaytracing:
     # ---- streaming read-back: frames in flight AND copied out (rt_read_pixels_async) -----------
     def host_frames(self, n):
         """n pinned (H, W, 4) uint8 frames for read_pixels_async (freed by close())."""
+        import weakref
         nbytes = self.height * self.width * 4
         out = []
         for _ in range(n):
             p = ctypes.c_void_p()
             abi.check(self._lib.rt_host_alloc(nbytes, ctypes.byref(p)))
-            self._pinned.append(p)
             buf = (ctypes.c_uint8 * nbytes).from_address(p.value)
+            # the pinned memory lives as long as anything refers to it -- the arrays handed out (numpy keeps `buf` as their
+            # base) or this renderer -- and is freed when the last reference goes, not at close(): a view that outlives the
+            # renderer stays valid
+            weakref.finalize(buf, self._lib.rt_host_free, ctypes.c_void_p(p.value))
+            self._pinned.append(buf)
             out.append(np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 4))
         return out
 
@@ -194,14 +199,11 @@ class RendererRaytracing:
         return out
 
     def close(self):
-        """Destroys the context.  The pinned frames of host_frames() are freed too: arrays handed out by it must not be
-        used afterwards (copy what is to be kept)."""
+        """Destroys the context.  The pinned frames of host_frames() stay valid for as long as an array refers to them."""
         if self._ctx is not None:
             self._lib.rt_destroy(self._ctx)      # waits for every copy that was begun
             self._ctx = None
-            for p in self._pinned:
-                self._lib.rt_host_free(p)
-            self._pinned = []
+            self._pinned = []                    # the renderer's own references; the memory goes with the last view
 
     def __del__(self):
         try:
