@@ -45,12 +45,11 @@ struct rt_rebuild {
     std::vector<float> in_records;            // job (latest posted wins)
     uint32_t in_n = 0;
     std::vector<float> out_rec;               // result
-    std::vector<float> out_ball;
     std::vector<uint32_t> out_link;
     uint32_t out_n = 0, out_nodes = 0;
 
     void run() {
-        std::vector<float> records, rec, ball;
+        std::vector<float> records, rec;
         std::vector<uint32_t> link;
         for (;;) {
             uint32_t n;
@@ -62,10 +61,9 @@ struct rt_rebuild {
                 n = in_n;
                 pending = false;
             }
-            const uint32_t nodes = rt_bvh_build(records.data(), n, rec, link, rt_bvh_arity(), &ball);
+            const uint32_t nodes = rt_bvh_build(records.data(), n, rec, link, rt_bvh_arity());
             std::lock_guard<std::mutex> lk(m);
             out_rec.swap(rec);
-            out_ball.swap(ball);
             out_link.swap(link);
             out_n = n;
             out_nodes = nodes;
@@ -665,13 +663,12 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         if (rc != RT_OK) return rc;
         uint32_t nodes = c->bvh_nodes;
         if (!refit) {
-            nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link, rt_bvh_arity(), &c->h_bvh_ball);
+            nodes = rt_bvh_build(c->h_records.data(), c->n, c->h_bvh_rec, c->h_bvh_link, rt_bvh_arity());
             upload_topology = true;
         } else if (c->rebuild) {
             std::lock_guard<std::mutex> lk(c->rebuild->m);
             if (c->rebuild->ready && c->rebuild->out_n == c->n) {
                 c->h_bvh_rec.swap(c->rebuild->out_rec);
-                c->h_bvh_ball.swap(c->rebuild->out_ball);
                 c->h_bvh_link.swap(c->rebuild->out_link);
                 nodes = c->rebuild->out_nodes;
                 upload_topology = true;
@@ -680,9 +677,8 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         }
         if (nodes + 1u > c->bvh_cap) {
             (void)hipFree(c->d_bvh_rec); (void)hipFree(c->d_bvh_link);
-            c->d_bvh_rec = nullptr; c->d_bvh_ball = nullptr; c->d_bvh_link = nullptr; c->bvh_cap = 0;
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_rec), 2u * ((size_t)nodes + 1u) * sizeof(float4)));
-            c->d_bvh_ball = c->d_bvh_rec + ((size_t)nodes + 1u);
+            c->d_bvh_rec = nullptr; c->d_bvh_link = nullptr; c->bvh_cap = 0;
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_rec), ((size_t)nodes + 1u) * sizeof(float4)));
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bvh_link), ((size_t)nodes + 1u) * sizeof(uint32_t)));
             c->bvh_cap = nodes + 1u;
         }
@@ -801,14 +797,13 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         if (upload_topology) {
             const size_t nn = (size_t)c->bvh_nodes + 1u;
             RT_HIP(hipMemcpyAsync(c->d_bvh_rec, c->h_bvh_rec.data(), nn * sizeof(float4), hipMemcpyHostToDevice, s));
-            RT_HIP(hipMemcpyAsync(c->d_bvh_ball, c->h_bvh_ball.data(), nn * sizeof(float4), hipMemcpyHostToDevice, s));
             RT_HIP(hipMemcpyAsync(c->d_bvh_link, c->h_bvh_link.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, s));
             RT_HIP(hipStreamSynchronize(s));   // pageable sources: the vectors may be rebuilt later
             c->bvh_topo_n = c->n;
         }
         // bounds of the inner nodes for the current positions (a topology from the worker was built for older ones)
-        if (refit) RT_HIP(rt_launch_bvh_refit(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, c->d_records, c->d_bvh_ball, s));
-        RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, fa.geo_f, c->d_bvh_ball, c->d_records, s));
+        if (refit) RT_HIP(rt_launch_bvh_refit(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, c->d_records, s));
+        RT_HIP(rt_launch_bvh_fill(c->d_bvh_rec, c->d_bvh_link, c->bvh_nodes, fa.geo_f, s));
         c->bvh_valid = true;
     }
     if (need_prep || need_bvh) {
@@ -816,7 +811,6 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         c->scene_stream = s;
     }
     fa.bvh_rec = use_bvh ? c->d_bvh_rec : nullptr;
-    fa.bvh_ball = use_bvh ? c->d_bvh_ball : nullptr;
     fa.bvh_link = use_bvh ? c->d_bvh_link : nullptr;
     fa.bvh_nodes = use_bvh ? c->bvh_nodes : 0u;
     // frames in flight on DIFFERENT streams run concurrently and share the chip: this frame's grid is
@@ -1177,18 +1171,6 @@ int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* 
     if (cap_nodes < nodes + 1u || !rec4 || !link) return fail(RT_ERR_CAPACITY, "rt_build_hierarchy: need n_nodes + 1 entries");
     std::memcpy(rec4, r.data(), r.size() * sizeof(float));
     std::memcpy(link, l.data(), l.size() * sizeof(uint32_t));
-    return RT_OK;
-}
-
-int rt_build_hierarchy_bounds(const float* records, uint32_t n, float* ball4, uint32_t cap_nodes, uint32_t* n_nodes) {
-    if ((n && !records) || !n_nodes) return fail(RT_ERR_INVALID_ARG, "rt_build_hierarchy_bounds: NULL argument");
-    std::vector<float> r, b;
-    std::vector<uint32_t> l;
-    const uint32_t nodes = rt_bvh_build(records, n, r, l, rt_bvh_arity(), &b);
-    *n_nodes = nodes;
-    if (l.empty()) return RT_OK;
-    if (cap_nodes < nodes + 1u || !ball4) return fail(RT_ERR_CAPACITY, "rt_build_hierarchy_bounds: need n_nodes + 1 entries");
-    std::memcpy(ball4, b.data(), b.size() * sizeof(float));
     return RT_OK;
 }
 

@@ -94,7 +94,6 @@
 // emulated fp32, against the literal test on rays built to graze (tests/test_hierarchy_walk_cpu.py).
 #include <algorithm>
 #include <cmath>
-#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -139,55 +138,25 @@ __host__ __device__ inline uint32_t bvh_lds_l0(uint32_t n_nodes, uint32_t base) 
     return (l0 + 15u) & ~15u;
 }
 // The 4x rule leaves [1024, l0) unused: the `best` slots (512 bytes per wave) of as many waves as fit go there -- at C5 thirteen
-// of sixteen, which is what lets the 16-wave form keep eight-entry lists beside 120 KB of nodes.
+// of sixteen.
 __host__ __device__ inline uint32_t bvh_gap_waves(uint32_t n_nodes, uint32_t waves) {
     const uint32_t k = (bvh_lds_l0(n_nodes, 0u) - 1024u) / 512u;
     return k < waves ? k : waves;
 }
+// bytes of one wave's candidate lists: nodes in LDS: CAP rows of 64 two-byte entries and the spare row the pooling needs
+// (trace_bvh: drain); nodes in global memory: CAP rows of 64 four-byte entries
+__host__ __device__ constexpr uint32_t bvh_list_bytes(bool nlds, uint32_t cap) { return nlds ? 128u * (cap + 1u) : 256u * cap; }
 __host__ __device__ inline uint32_t bvh_lds_lists(uint32_t n_nodes, uint32_t base) {   // byte offset of the lists
     const uint32_t l0 = bvh_lds_l0(n_nodes, base);
     return 4u * (base + l0) - base + 16u * ((n_nodes + 4u) & ~3u);
 }
 
-// The COMPACT form (CMP; 12-wave workgroups, two per CU, for scenes whose 20-byte nodes leave room for one workgroup only):
-// a node is 8 bytes of record + 2 bytes of link, in a layout that is the same for every scene --
-//   [0, 1024) the x/255 table | [1024, 7168) the waves' `best` slots | records from kCmpR0 | links | candidate lists --
-// sized for cmp_nmax(CAP) nodes: 2 x 81,920 bytes are the whole LDS of a CU.  Record: {cx, cy} and {cz, K} as two dwords --
-// the centre in f16 (read by v_fma_mix_f32 without a conversion of their own), K = (R 2^-12)^2 in the HIGH half of the
-// second dword: that dword, read as an f32, is K with cz's bits below its eighth mantissa bit -- a value in [K, K (1 + 2^-7)),
-// never below K.  Link (u16): a leaf's sphere index (< kCmpR0), an inner node's skip target as the LDS address of its record.
-constexpr uint32_t kCmpR0 = 7168u;
-#ifndef RT_BVH_CMP_BYTES
-#define RT_BVH_CMP_BYTES 80640u   /* 63 granules of 1280 bytes */
-#endif
-constexpr uint32_t kCmpBytes = RT_BVH_CMP_BYTES;
-__host__ __device__ constexpr uint32_t cmp_slots(int cap) { return ((kCmpBytes - kCmpR0 - 12u * 256u * (uint32_t)cap) / 10u) & ~1u; }   // node slots (sentinel included), even
-__host__ __device__ constexpr uint32_t cmp_nmax(int cap) { return cmp_slots(cap) - 1u; }
-__host__ __device__ constexpr uint32_t cmp_links(int cap) { return kCmpR0 + 8u * cmp_slots(cap); }        // byte address of the link array
-__host__ __device__ constexpr uint32_t cmp_lists(int cap) { return cmp_links(cap) + 2u * cmp_slots(cap); } // ... of the candidate lists
-static_assert(cmp_lists(6) + 12u * 256u * 6u <= kCmpBytes && cmp_lists(5) + 12u * 256u * 5u <= kCmpBytes && cmp_lists(4) + 12u * 256u * 4u <= kCmpBytes, "compact layout");
-static_assert(kCmpR0 + 8u * cmp_slots(4) <= 65536u, "record addresses are 16-bit links");
-#define RT_BVH_CMP_S 2.44140625e-04f        /* 2^-12: scale of the compact node test (|T| < 2^12 under the sign-aware form's reach) */
-#define RT_BVH_CMP_S2 5.9604644775390625e-08f   /* 2^-24 */
-
 // ---- device: leaf records = the filter records prep_spheres wrote ------------------------------------
-// (double, positive) -> float, rounded up
-__device__ __forceinline__ float f32_up(double v) {
-    float f = (float)v;
-    if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + 1u);
-    return f;
-}
-// ball: the plain bounds {C, R} the compact form is made from (bvh_pixels<..., CMP>): a leaf's is its sphere about its own
-// centre, times sigma like an inner node's -- to the compact walk a leaf is a node with one member.
-__global__ void bvh_fill_leaves(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, float4* ball, const float* records) {
+__global__ void bvh_fill_leaves(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const uint32_t l = link[i];
-    if (l & 0x80000000u) {
-        rec[i] = geo_f[l & 0x7FFFFFFFu];
-        const float* s = records + 8u * (size_t)(l & 0x7FFFFFFFu);
-        ball[i] = make_float4(s[0], s[1], s[2], f32_up(fabs((double)s[7]) * RT_BVH_SIGMA));     // NaN stays NaN: never passes
-    }
+    if (l & 0x80000000u) rec[i] = geo_f[l & 0x7FFFFFFFu];
 }
 
 // ---- device: node bounds for moved spheres (same topology) ----------------------------------------------
@@ -213,7 +182,7 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 }
 
 __global__ __launch_bounds__(256) void bvh_refit(float4* __restrict__ rec, const uint32_t* __restrict__ link,
-                                                  uint32_t n_nodes, const float* __restrict__ records, float4* __restrict__ ball) {
+                                                  uint32_t n_nodes, const float* __restrict__ records) {
     const uint32_t node = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (node >= n_nodes) return;
     const uint32_t lk = link[node];
@@ -274,11 +243,9 @@ __global__ __launch_bounds__(256) void bvh_refit(float4* __restrict__ rec, const
     R *= RT_BVH_SIGMA;
     const double c2 = Cd[0] * Cd[0] + Cd[1] * Cd[1] + Cd[2] * Cd[2];
     const double k = c2 * (1.0 - (double)RT_FILTER_EPS) - R * R * (1.0 + (double)RT_FILTER_KAPPA);
-    if (lane == 0) {
+    if (lane == 0)
         rec[node] = make_float4(C[0] * RT_FILTER_SCALE, C[1] * RT_FILTER_SCALE, C[2] * RT_FILTER_SCALE,
                                 (float)(k * (double)RT_FILTER_SCALE2));
-        ball[node] = make_float4(C[0], C[1], C[2], f32_up(R));
-    }
 }
 
 #ifdef RT_BVH_COUNT
@@ -334,7 +301,7 @@ __device__ __forceinline__ void reversed_shadow_walk(bool shadow, v3 L, float li
 // completed and fewer than TAIL lanes are still walking, the call returns; the stragglers resume
 // in the next call, next to the fresh rays of the lanes that completed -- the long tail of a
 // wave's slowest rays no longer holds 64 lanes for a handful.
-template <bool SGN, bool NLDS, int CAP, bool ROOMY, bool CMP = false>
+template <bool SGN, bool NLDS, int CAP, bool ROOMY>
 __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __restrict__ R, const uint32_t* __restrict__ L, uint32_t n,
                                           const float4* __restrict__ geo, uint32_t* slot, unsigned long long* best,
                                           uint32_t& i, v3 o, v3 d, v3 wo, v3 wd, float madd, float& nearest, int& idx
@@ -362,17 +329,9 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
     const v3 hs = V(h.x * kT, h.y * kT, h.z * kT);
     const v3 ms = V(m.x * kT2, m.y * kT2, m.z * kT2);
     const float ps = -p * kT, qs = q * kT2;
-    // CMP (the compact form, see kCmpR0): a node is a ball {C', K = (R 2^-12)^2} and the test is made about ITS centre --
-    //   oc = (C' - wo) 2^-12 (three v_fma_mix_f32: the f16 coordinate times 2^-12, exact, minus the scaled origin: one rounding),
-    //   nb = max(h.oc, 0) (the clamp of the FMA that completes it: |h.oc| < 1 by the scale), pass iff nb^2 - (|oc|^2 - K) > -madd 2^-24.
-    // Conservative like the filter's test: the computed value differs from (1 + kappa_h)^2 T^2 - |wo - C'|^2 + R^2 (scaled) by less
-    // than 17 u (|wo - C'|^2 + R^2) -- oc: u per component; both dot products: 3 u more; the square and the two sums: 3 u --, which
-    // the header's argument has room for where it allows 14 u for the filter's form (near origins: 0.0035 R^2 to spare against
-    // 17 u * 1025 R^2 = 0.001 R^2; far origins: under 2 kappa_h T^2), and K is never below (R 2^-12)^2.
-    const v3 nw = V(-wo.x * RT_BVH_CMP_S, -wo.y * RT_BVH_CMP_S, -wo.z * RT_BVH_CMP_S);
-    const float negm = -madd * RT_BVH_CMP_S2;
     // this lane's candidate column in LDS: entries 256 bytes apart; wa = LDS address of the next free one
     typedef __attribute__((address_space(3))) uint32_t* lds_u32_w;
+    typedef __attribute__((address_space(3))) uint16_t* lds_u16_w;
     const uint32_t wa0 = (uint32_t)(uintptr_t)slot;
     uint32_t wa = wa0;
 
@@ -385,19 +344,49 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
     // result into the owner's slot of `best` with an LDS 64-bit atomic min on (t bits, sphere index) -- the
     // lexicographic minimum the in-order `t < nearest` loop of the reference keeps (t > 0, so its bit
     // pattern orders like its value; "no hit yet" is index 0xFFFFFFFF, which loses every tie).
-    // POOL (the compact form): the wave's lanes append to ONE list -- a lane's place is the wave's count plus its rank among
-    // the lanes that append in that step (ballot, mbcnt), the entry carries its owner -- so the room the waves' lists take
-    // serves the wave's total, not sixty-four times the longest list, and the evaluation finds them pooled already.
-    constexpr bool POOL = CMP;
-    uint32_t pc = 0;                                                     // POOL: entries in the wave's list (wave-uniform)
-    // POOL, a drain in mid-walk: whole rows of 64 only -- every lane of every pass of the evaluation has an item --, what is
-    // left (< 64 entries) moves to the front of the list and waits for the next drain; the last drain of the call takes all.
-    auto drain = [&](const bool last) {
+    // L16 (every form with its nodes in LDS: a sphere index fits 16 bits there): list entries are two bytes -- a lane's list is
+    // twice as long in the same LDS, and the evaluation below is entered half as often (eight -> twelve entries per lane:
+    // -5 % on scenes of 2000-3400 spheres, six -> eight: -10 %; profiles/r04/bvh_cap_sweep.log).  The pool's four-byte items
+    // (owner, sphere) no longer fit where the rows they come from were, front to back; they are written from the END of the
+    // wave's list area downwards while the rows are taken from the LAST one down -- the long rows are the sparse ones --,
+    // one spare row above the lists guarantees room for the first, and when the pool would reach a row not yet read
+    // (4 (total + row) > 128 (CAP + 1 - k) bytes: all lists full), what is pooled is evaluated first and the pool starts over.
+    constexpr bool L16 = NLDS;
+    typedef __attribute__((address_space(3))) const uint16_t* lds_u16;
+    typedef __attribute__((address_space(3))) const uint32_t* lds_u32r;
+    auto drain = [&]() {
         const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t cnt = POOL ? 0u : (wa - wa0) >> 8;
-        uint32_t* const pool = POOL ? slot : slot - lane;                // this wave's list area, as a linear array
-        uint32_t total = POOL ? (last ? pc : pc & ~63u) : 0u;            // wave-uniform
-        for (uint32_t k = 0; !POOL; ++k) {
+        const uint32_t cnt = L16 ? (wa - wa0) >> 7 : (wa - wa0) >> 8;
+        uint32_t* const pool = slot - lane;                              // (!L16) this wave's list area, as a linear array
+        const uint32_t top = wa0 - 2u * lane + 128u * (uint32_t)(CAP + 1);   // (L16) LDS address of the end of the wave's list area
+        uint32_t total = 0;                                              // wave-uniform
+        uint32_t lim = cnt;                                              // (L16) rows [0, lim) of this lane's list are still to be taken
+        uint32_t again = 0;                                              // (L16) wave-uniform: rows were left for another round
+        best[lane] = ((unsigned long long)__float_as_uint(nearest) << 32) | (unsigned long long)(uint32_t)idx;
+      for (;;) {
+        if (L16) {
+            // (unrolled: the row number is a constant of each copy; total, kstop are scalars the compiler keeps scalar)
+            total = 0;
+            uint32_t kstop = 0;
+            bool stopped = false;
+#pragma unroll
+            for (int k = CAP - 1; k >= 0; --k) {
+                const uint64_t m = __ballot((uint32_t)k < lim);
+                if (m == 0ull) continue;
+                const uint32_t need = (uint32_t)__popcll(m);
+                if (!stopped && 4u * (total + need) > 128u * (uint32_t)(CAP + 1 - k)) { stopped = true; kstop = (uint32_t)k + 1u; }   // the pool would reach row k - 1
+                if (stopped) continue;
+                uint32_t e = 0;
+                if ((uint32_t)k < lim) e = *(lds_u16)(uintptr_t)(wa0 + 128u * (uint32_t)k);      // every lane reads row k before any lane writes
+                const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if ((uint32_t)k < lim) *(lds_u32_w)(uintptr_t)(top - 4u - 4u * pos) = (lane << 24) | e;
+                total += need;
+                asm volatile("" : "+s"(total));                        // (stays in a scalar register between the rows)
+            }
+            again = stopped ? 1u : 0u;
+            if (stopped) lim = lim < kstop ? lim : kstop;                // rows from kstop up are in the pool now
+        } else {
+        for (uint32_t k = 0;; ++k) {
             const uint64_t m = __ballot(k < cnt);
             if (m == 0ull) break;
             uint32_t e = 0;
@@ -406,13 +395,13 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
             if (k < cnt) pool[pos] = (lane << 24) | (e & 0x00FFFFFFu);   // pos < 64 (k + 1): rows > k are untouched
             total += (uint32_t)__popcll(m);
         }
-        best[lane] = ((unsigned long long)__float_as_uint(nearest) << 32) | (unsigned long long)(uint32_t)idx;
+        }
         for (uint32_t i = lane; __ballot(i < total) != 0ull; i += 64u) {
 #ifdef RT_BVH_COUNT
             if (RT_BVH_COUNT == 4) g_steps += lane == 0u ? 1u : 0u;                    // drain iterations (wave)
             if (RT_BVH_COUNT == 5) g_steps += i < total ? 1u : 0u;                     // candidates evaluated (lane)
 #endif
-            const uint32_t e = i < total ? pool[i] : (lane << 24);
+            const uint32_t e = i < total ? (L16 ? *(lds_u32r)(uintptr_t)(top - 4u - 4u * i) : pool[i]) : (lane << 24);
             const int owner = (int)(e >> 24);
             const int si = (int)(e & 0x00FFFFFFu);
             // The candidate's exact record is requested BEFORE the six shuffles, not behind them (the compiler sinks an
@@ -437,16 +426,13 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
                 }
             }
         }
+        if (!L16 || __builtin_amdgcn_readfirstlane((int)again) == 0) break;
+      }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const unsigned long long r = best[lane];
         nearest = __uint_as_float((uint32_t)(r >> 32));
         idx = (int)(uint32_t)r;
         wa = wa0;
-        if (POOL) {
-            const uint32_t rest = pc - total;                            // < 64 unless last (then 0)
-            if (lane < rest) pool[lane] = pool[total + lane];            // total >= 64 here: no lane writes what another reads
-            pc = rest;
-        }
     };
 
     // The walk's state j is an address.  Nodes staged in LDS: the LDS address of the node's RECORD, 16 x node index + 4 x
@@ -465,17 +451,8 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
     // One step in three parts, so that a trip can issue the NEXT node's loads before it appends the current leaf: the
     // append is an exec-masked block of its own, and a wave issues in order -- with the loads behind it, every step
     // waited for six scalar and vector instructions that the next test does not depend on (round 3).
-    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
     auto fetch = [&](uint32_t j, float4& g, uint32_t& lk) {
-        if (CMP) {
-            // Both reads by hand: the compiler reads a u16 into a register whose upper half it then clears again with a
-            // v_and in the block that uses it -- on the path from a link to the next record's address.  ds_read_u16 has
-            // cleared it.  The wait is ours as well (landed(), before every use and before the registers die).
-            u2v gv;
-            asm volatile("ds_read_b64 %0, %2\n\tds_read_u16 %1, %3 offset:%4"
-                         : "=&v"(gv), "=&v"(lk) : "v"(j), "v"(j >> 2), "n"(cmp_links(CAP) - kCmpR0 / 4u));     // the constant rides in the offset field
-            g.x = __uint_as_float(gv.x); g.y = __uint_as_float(gv.y);
-        } else if (NLDS) {
+        if (NLDS) {
             const f4v gv = *(lds_f4)(uintptr_t)j;
             lk = *(lds_u32)(uintptr_t)(j >> 2);                   // bvh_lds_l0: the records sit at 4 x the links' address
             g = make_float4(gv.x, gv.y, gv.z, gv.w);
@@ -484,21 +461,8 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
             g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R) + 4u * (size_t)j);
         }
     };
-    auto landed = [&](float4& g, uint32_t& lk) {       // CMP: the hand-issued reads of fetch() have arrived
-        if (CMP) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g.x), "+v"(g.y), "+v"(lk));
-    };
     auto passes = [&](const float4& g) -> bool {
-        if (CMP) {
-            float ocx, ocy, ocz, nb;
-            const float sc = RT_BVH_CMP_S;
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ocx) : "v"(g.x), "s"(sc), "v"(nw.x));
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ocy) : "v"(g.x), "s"(sc), "v"(nw.y));
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ocz) : "v"(g.y), "s"(sc), "v"(nw.z));
-            const float part = fma_vvv(ocy, h.y, ocx * h.x);
-            asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nb) : "v"(ocz), "v"(h.z), "v"(part));
-            const float q3 = fma_vvv(ocz, ocz, fma_vvv(ocy, ocy, __builtin_fmaf(ocx, ocx, -g.y)));
-            return __builtin_fmaf(nb, nb, -q3) > negm;
-        } else if (CLAMPED) {
+        if (CLAMPED) {
             float nb;      // max(-b, 0) * 2^-62
             const float part = fma_vvv(hs.y, g.y, fma_vvv(hs.x, g.x, ps));
             asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nb) : "v"(hs.z), "v"(g.z), "v"(part));
@@ -511,18 +475,11 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
             return __builtin_fmaf(bm, bm, -q) > cp;
         }
     };
-    const uint32_t lane_hi = (threadIdx.x & 63u) << 24;
-    const uint32_t slot_s = POOL ? __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)slot) : 0u;
-    auto append = [&](uint32_t lk, uint32_t pc0) {
-        if (POOL) {
-            const uint64_t am = __ballot(true);                          // the lanes of this step that append
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-            // where the wave's next entry goes is a scalar, formed in the scalar unit (the compiler adds count and rank in the
-            // vector unit otherwise): one shift-and-add gives the lane's address
-            uint32_t at;
-            asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(at) : "s"(pc0), "s"(slot_s) : "scc");
-            *(lds_u32_w)(uintptr_t)(at + 4u * rank) = lane_hi | lk;
-        } else if (NLDS) {   // the store and the advance in place: the compiler forms the new address in a second register and moves it back
+    auto append = [&](uint32_t lk) {
+        if (L16) {    // the store and the advance in place: the compiler forms the new address in a second register and moves it back
+            *(lds_u16_w)(uintptr_t)wa = (uint16_t)lk;                    // the sphere index: the low half of a leaf's link
+            asm("v_add_u32_e32 %0, 0x80, %0" : "+v"(wa));
+        } else if (NLDS) {
             *(lds_u32_w)(uintptr_t)wa = lk;
             asm("v_add_u32_e32 %0, 0x100, %0" : "+v"(wa));
         } else {
@@ -530,8 +487,8 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
             wa += 256u;
         }
     };
-    const uint32_t jn = CMP ? kCmpR0 + 8u * n : (NLDS ? 4u * (4u * n + l0) : 4u * n);
-    uint32_t j = CMP ? kCmpR0 + 8u * i : (NLDS ? 4u * (4u * i + l0) : 4u * i);
+    const uint32_t jn = NLDS ? 4u * (4u * n + l0) : 4u * n;
+    uint32_t j = NLDS ? 4u * (4u * i + l0) : 4u * i;
     // Loop control in the scalar unit, one exit test per trip: the wave leaves when no lane walks any more, or -- once
     // some lane has finished -- when fewer than `tail` still do (`tail` >= 1 covers the first case whenever the loop was
     // entered; tail == 0, "never suspend", leaves through the loop condition).
@@ -546,9 +503,8 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
 #endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            landed(g, lk);
             const bool pass = passes(g);
-            const bool leaf = CMP ? lk < kCmpR0 : (int)lk < 0;
+            const bool leaf = (int)lk < 0;
 #ifdef RT_BVH_COUNT
             if (RT_BVH_COUNT == 2) g_steps += j != jn ? 1u : 0u;
             if (RT_BVH_COUNT == 6) g_steps += leaf ? 1u : 0u;                              // leaf tests (lane)
@@ -556,23 +512,19 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
             if (RT_BVH_COUNT == 8) g_steps += (!leaf && lk != j) ? 1u : 0u;                // inner nodes tested (lane; the sentinel links to itself)
 #endif
             const uint32_t here = lk;
-            const uint32_t pc0 = pc;                                     // POOL: where this step's entries go ...
-            if (POOL) pc += (uint32_t)__popcll(__ballot(leaf) & __ballot(pass));     // ... (two ballots of two compares, in the compares' block: each IS its compare's mask)
-            j = (leaf || pass) ? j + (CMP ? 8u : (NLDS ? 16u : 4u)) : lk;     // staged links are record addresses already
+            j = (leaf || pass) ? j + (NLDS ? 16u : 4u) : lk;     // staged links are record addresses already
             fetch(j, g, lk);
-            if (leaf && pass) append(here, pc0);
+            if (leaf && pass) append(here);
         }
-        if (__builtin_expect(POOL ? pc > 64u * (uint32_t)CAP - 256u : __ballot(wa >= wa0 + 256u * (uint32_t)(CAP - 3)) != 0ull, 0)) {   // room for the four entries (POOL: 4 x 64) of the next trip
-            if (!ROOMY) landed(g, lk);        // (their registers are about to be given away)
-            drain(CAP < 5);                   // (a list of 256 has no room to keep a rest beside the next trip's entries)
+        if (__builtin_expect(__ballot(wa >= wa0 + (L16 ? 128u : 256u) * (uint32_t)(CAP - 3)) != 0ull, 0)) {   // room for the four entries of the next trip
+            drain();
             if (!ROOMY) fetch(j, g, lk);      // again, rather than five registers kept alive across the evaluation (80-VGPR forms: 10 spilled otherwise)
         }
         walking = __ballot(j != jn);
         if (walking != walking0 && (uint32_t)__builtin_popcountll(walking) < tail) break;
     }
-    landed(g, lk);
-    drain(true);
-    i = CMP ? (j - kCmpR0) >> 3 : (NLDS ? ((j >> 2) - l0) >> 2 : j >> 2);
+    drain();
+    i = NLDS ? ((j >> 2) - l0) >> 2 : j >> 2;
 }
 
 // ---- kernel ---------------------------------------------------------------------------------------------
@@ -587,7 +539,7 @@ inline bool lds_fits(size_t k, size_t bytes) { return k * ((bytes + 1279u) / 128
 // chain of dependent LDS reads, and the extra waves hide it (3.93 vs 4.40 ms at C3); 16-wave
 // workgroups serve scenes whose nodes leave room for one workgroup per CU only (4 waves per SIMD).
 // FLAT: compiled for a one-colour 1x1 sky (A.sky_flat; C1-C4) -- no cube filtering code in the kernel.
-template <int WAVES, bool SGN, bool NLDS, int CAP, bool FLAT, bool CMP = false>
+template <int WAVES, bool SGN, bool NLDS, int CAP, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(const RtFrameArgs A) {
     extern __shared__ float4 lds[];
     const uint32_t n = A.bvh_nodes;               // the arrays hold n + 1 entries: [n] is the sentinel
@@ -598,48 +550,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
     const uint32_t l0off = bvh_lds_l0(n, base);
     uint32_t* sL = reinterpret_cast<uint32_t*>(lds_b + (NLDS ? l0off : 0u));
     float4* sR = reinterpret_cast<float4*>(lds_b + (NLDS ? 4u * (base + l0off) - base : 0u));
-    uint32_t* lists = reinterpret_cast<uint32_t*>(lds_b + (CMP ? cmp_lists(CAP) : (NLDS ? bvh_lds_lists(n, base) : 1024u)));
+    uint32_t* lists = reinterpret_cast<uint32_t*>(lds_b + (NLDS ? bvh_lds_lists(n, base) : 1024u));
     (void)n4;
     // the host sized the allocation for dynamic LDS at address 0 (no static LDS in this kernel); anything else is
     // reported, not rendered: rt_wait fails the frame (rt_device.h: report_fault)
     if (NLDS && base != 0u) { report_fault(A.rays, 1ull); return; }
-    if (CMP) {
-        static_assert(!CMP || (WAVES == 12 && SGN && NLDS), "the compact form: 12 waves, sign-aware, staged");
-        if (n > cmp_nmax(CAP)) { report_fault(A.rays, 2ull); return; }        // (the host chose the form by the node count)
-        // Staged from the plain bounds {C, R}: C' = C rounded to f16 (a result below 2^-14 in magnitude becomes 0: no subnormal
-        // f16 reaches v_fma_mix_f32), R' = R + sigma |C' - C|_1 -- the ball about C' that contains the ball about C, sigma
-        // because R carries it --, a shade more for the roundings here, K = (R' 2^-12)^2 rounded UP to the 16 bits it keeps.
-        uint2* const cR = reinterpret_cast<uint2*>(lds_b + kCmpR0);
-        uint16_t* const cL = reinterpret_cast<uint16_t*>(lds_b + cmp_links(CAP));
-        for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) {
-            const float4 b = A.bvh_ball[i];
-            const uint32_t lk = A.bvh_link[i];
-            float back[3];
-            uint32_t hb[3];
-            const float in[3] = {b.x, b.y, b.z};
-            bool wide = false;                                   // a coordinate beyond f16: the node passes every ray
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                _Float16 hv = (_Float16)in[a];
-                float f = (float)hv;
-                if (__builtin_fabsf(f) > 65504.0f) { wide = true; f = 0.0f; hv = (_Float16)0.0f; }
-                if (!(__builtin_fabsf(f) >= 6.103515625e-05f)) { f = in[a] != in[a] ? in[a] : 0.0f; hv = (_Float16)0.0f; }   // a NaN centre keeps the node shut (below)
-                back[a] = f;
-                unsigned short us;
-                __builtin_memcpy(&us, &hv, 2);
-                hb[a] = us;
-            }
-            const float e1 = (__builtin_fabsf(back[0] - b.x) + __builtin_fabsf(back[1] - b.y)) + __builtin_fabsf(back[2] - b.z);
-            const float Rc = (b.w + 1.0401f * e1) * 1.000002f;
-            const float Ks = Rc * RT_BVH_CMP_S;
-            const float K = (Ks * Ks) * 1.000001f;
-            uint32_t kh = (__float_as_uint(K) + 0xFFFFu) >> 16;
-            if (kh > 0x7F80u || wide) kh = 0x7F80u;              // +inf: always passes
-            if (!(Rc >= 0.0f)) kh = 0xFF80u;                     // the sentinel (R = -inf) and NaN bounds: -inf, never passes
-            cR[i] = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (kh << 16));
-            cL[i] = (uint16_t)((int)lk < 0 ? (lk & 0x7FFFFFFFu) : kCmpR0 + 2u * lk);     // lk = 4 x node index: its record at R0 + 8 x index
-        }
-    } else if (NLDS)
+    if (NLDS)
         for (uint32_t i = threadIdx.x; i <= n; i += 64 * WAVES) {
             float4 r = A.bvh_rec[i];
             if (SGN) r.w *= 4.70197740328915e-38f;      // 2^-124: the clamped form of the node test (trace_bvh)
@@ -649,12 +565,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
         }
     const float4* R = NLDS ? sR : A.bvh_rec;
     const uint32_t* L = NLDS ? sL : A.bvh_link;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* slot = lists + wave * (uint32_t)(CAP * 64) + (CMP ? 0u : lane);     // CMP: the wave's pooled list
-    // per wave: 64 x (t bits, sphere index), the running nearest hits of the pooled literal evaluation (trace_bvh: drain)
-    const uint32_t gapw = (NLDS && !CMP) ? bvh_gap_waves(n, (uint32_t)WAVES) : 0u;      // waves whose slots sit in the gap under the links
-    unsigned long long* best = (CMP || wave < gapw) ? reinterpret_cast<unsigned long long*>(lds_b + 1024u) + wave * 64u
-                                                    : reinterpret_cast<unsigned long long*>(lists + WAVES * CAP * 64) + (wave - gapw) * 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // a scalar, and so is all that derives from it
+    constexpr uint32_t kListBytes = bvh_list_bytes(NLDS, (uint32_t)CAP);
+    uint32_t* slot = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lists) + wave * kListBytes + lane * (NLDS ? 2u : 4u));   // (NLDS: used as an address only)
+    // per wave: 64 x (t bits, sphere index), the running nearest hits of the pooled literal evaluation (trace_bvh: drain);
+    // the first bvh_gap_waves() waves' under the links, the others' behind the lists
+    const uint32_t gapw = NLDS ? bvh_gap_waves(n, (uint32_t)WAVES) : 0u;
+    unsigned long long* best = wave < gapw ? reinterpret_cast<unsigned long long*>(lds_b + 1024u) + wave * 64u
+                                           : reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lists) + WAVES * kListBytes) + (wave - gapw) * 64u;
     // rgba8unorm -> float table for the cube map texels: the reference's x / 255 division done
     // 256 times per workgroup instead of 12 times per sample
     float* lut = reinterpret_cast<float*>(lds_b);                          // the first KiB
@@ -781,10 +700,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 4 : 6) void bvh_pixels(co
         else if (shadow) wo = sc.lightPos;
 #ifdef RT_BVH_COUNT
         if (RT_BVH_COUNT == 3) nrays += lane == 0u ? 1u : 0u;                          // outer iterations (wave)
-        trace_bvh<SGN, NLDS, CAP, WAVES == 16, CMP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx, nrays);
+        trace_bvh<SGN, NLDS, CAP, WAVES == 16>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx, nrays);
         if (walking && node == n) {
 #else
-        trace_bvh<SGN, NLDS, CAP, WAVES == 16, CMP>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx);
+        trace_bvh<SGN, NLDS, CAP, WAVES == 16>(A.bvh_tail, R, L, n, A.geo, slot, best, node, shadow ? sc.lightPos : ro, shadow ? sdir : rd, wo, wd, madd, t, idx);
         if (walking && node == n) {                                      // this lane's ray is complete
             ++nrays;
 #endif
@@ -896,7 +815,7 @@ __global__ __launch_bounds__(256) void sky_resolve(const RtFrameArgs A) {
     }
 }
 
-template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL, bool CMP = false>
+template <int WAVES, bool SGN, bool NLDS, int CAP, int TAIL>
 hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     // The walk is left for the shading pass once fewer than `tail` lanes still walk.  A frame that has the
     // chip to itself prefers a lower threshold than frames that share it (C3, tools/knob_ab.py: one frame at a
@@ -911,7 +830,7 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_TAIL")) a.bvh_tail = (uint32_t)atoi(e);
 #endif
-    auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, true, CMP> : bvh_pixels<WAVES, SGN, NLDS, CAP, false, CMP>;
+    auto k = a.sky_flat ? bvh_pixels<WAVES, SGN, NLDS, CAP, true> : bvh_pixels<WAVES, SGN, NLDS, CAP, false>;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -937,18 +856,13 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
     if (blocks > need) blocks = need;
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_BLOCKS")) if (atoi(e) > 0) blocks = std::min((uint32_t)atoi(e), need);
-    if (getenv("RT355_BVH_PRINT")) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), 64 * WAVES, lds);
-        fprintf(stderr, "bvh_pixels<%d waves, cap %d, cmp %d>: lds %zu, blocks %u, per_cu %u, runtime says %d per CU\n", WAVES, CAP, (int)CMP, lds, blocks, per_cu, nb);
-    }
     if (const char* e = getenv("RT355_BVH_LDS_PAD")) {          // extra dynamic LDS: where does the third workgroup per CU go?
         lds += (size_t)atoi(e);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
 #endif
     if (!a.sky_flat && !a.fin) return hipErrorInvalidValue;
-    g_rt_kernel_id = CMP ? RT_KID_HIERARCHY_12C : (!NLDS ? RT_KID_HIERARCHY_GLOBAL : (WAVES == 8 ? RT_KID_HIERARCHY_8 : (WAVES == 12 ? RT_KID_HIERARCHY_12 : RT_KID_HIERARCHY_16)));
+    g_rt_kernel_id = !NLDS ? RT_KID_HIERARCHY_GLOBAL : (WAVES == 8 ? RT_KID_HIERARCHY_8 : (WAVES == 12 ? RT_KID_HIERARCHY_12 : RT_KID_HIERARCHY_16));
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * WAVES), lds, s, a);
     if (!a.sky_flat) return rt_launch_sky_resolve(a, s);
     return hipGetLastError();
@@ -957,45 +871,38 @@ hipError_t launch_bvh_as(const RtFrameArgs& a0, size_t lds, hipStream_t s) {
 template <bool SGN>
 hipError_t launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
-    constexpr int CAP = 8;
+    constexpr int CAP = 12;
     // dynamic LDS starts at address 0 of the workgroup's allocation (the kernels declare no static LDS);
     // the kernel re-derives the layout from the address it actually gets
     const size_t nodes = (size_t)bvh_lds_lists(a.bvh_nodes, 0u);        // table + links + records (+ the gap the 4x rule leaves)
     const size_t cap = 160u * 1024u;
-    // per wave: CAP x 64 candidate entries + 64 eight-byte slots of running nearest hits.  Scenes whose nodes
-    // leave room for one 16-wave workgroup only (C5: 128 KB of nodes) get six-entry lists: 2 KB per wave again.
-    // (the `best` slots of the first bvh_gap_waves() waves are inside `nodes`)
-    auto room = [&](uint32_t waves, uint32_t entries) { return nodes + (size_t)waves * entries * 256u + (size_t)(waves - bvh_gap_waves(a.bvh_nodes, waves)) * 512u; };
+    // per wave: the candidate lists (bvh_list_bytes) + 64 eight-byte slots of running nearest hits, those of the first
+    // bvh_gap_waves() waves inside `nodes`.  Lists of twelve entries per lane where they fit, of six where that keeps a form
+    // with more waves per SIMD (or the LDS form at all).
+    auto room = [&](uint32_t waves, uint32_t entries) {
+        return nodes + (size_t)waves * bvh_list_bytes(true, entries) + (size_t)(waves - bvh_gap_waves(a.bvh_nodes, waves)) * 512u;
+    };
+#ifdef RT_BVH_DEV_ENV
+    if (const char* e = getenv("RT355_BVH_CAP")) {      // how much do longer lists buy?  (8-wave form)
+        if (atoi(e) == 16 && lds_fits(3u, room(8u, 16u))) return launch_bvh_as<8, SGN, true, 16, RT_BVH_TAIL_SMALL>(a, room(8u, 16u), s);
+        if (atoi(e) == 8 && lds_fits(3u, room(8u, 8u))) return launch_bvh_as<8, SGN, true, 8, RT_BVH_TAIL_SMALL>(a, room(8u, 8u), s);
+        if (atoi(e) == 10 && lds_fits(3u, room(8u, 10u))) return launch_bvh_as<8, SGN, true, 10, RT_BVH_TAIL_SMALL>(a, room(8u, 10u), s);
+    }
+#endif
     if (lds_fits(3u, room(8u, CAP))) return launch_bvh_as<8, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, room(8u, CAP), s);
-    // two 12-wave workgroups per CU keep six waves per SIMD for scenes between the two forms (~1100-1500 spheres:
-    // 1200 / 1400 / 1500 spheres at 4K 2.58 / 2.83 / 2.88 -> 2.32 / 2.55 / 2.59 ms per frame in flight; with six-entry
-    // lists the window reaches ~1750 spheres: 1600 / 1700 spheres 2.90 / 2.95 -> 2.65 / 2.71 ms)
+    // two 12-wave workgroups per CU keep six waves per SIMD for scenes between the two forms
     if (lds_fits(2u, room(12u, CAP))) return launch_bvh_as<12, SGN, true, CAP, RT_BVH_TAIL_SMALL>(a, room(12u, CAP), s);
     if (lds_fits(2u, room(12u, 6u))) return launch_bvh_as<12, SGN, true, 6, RT_BVH_TAIL_SMALL>(a, room(12u, 6u), s);
-    // Beyond that the 20-byte nodes leave room for one workgroup per CU; the compact form (10 bytes per node, kCmpR0) keeps two
-    // and six waves per SIMD up to cmp_nmax(4) nodes -- sign-aware scenes only (their reach bounds every coordinate: the
-    // centres fit f16 and the scaled node test cannot leave the clamp's range).
-    if constexpr (SGN) {
-        // (measured, round 4: C5 16.1 ms one at a time / 17.0 in flight with six children per node -- its list leaves no room for
-        // more at four -- against 16.2 / 15.2 of the 16-wave form with eight-entry lists: development builds only)
-        bool compact = false;
-#ifdef RT_BVH_DEV_ENV
-        if (const char* e = getenv("RT355_BVH_CMP")) compact = a.bvh_ball != nullptr && atoi(e) != 0;
-#endif
-        if (compact && a.bvh_nodes <= cmp_nmax(6)) return launch_bvh_as<12, true, true, 6, RT_BVH_TAIL_LARGE, true>(a, kCmpBytes, s);
-        if (compact && a.bvh_nodes <= cmp_nmax(5)) return launch_bvh_as<12, true, true, 5, RT_BVH_TAIL_LARGE, true>(a, kCmpBytes, s);
-        if (compact && a.bvh_nodes <= cmp_nmax(4)) return launch_bvh_as<12, true, true, 4, RT_BVH_TAIL_LARGE, true>(a, kCmpBytes, s);
-    }
 #ifdef RT_BVH_DEV_ENV
     if (const char* e = getenv("RT355_BVH_CAP")) {      // how much do longer lists buy?  (16-wave form, scenes with room)
         if (atoi(e) == 16 && room(16u, 16u) <= cap) return launch_bvh_as<16, SGN, true, 16, RT_BVH_TAIL_LARGE>(a, room(16u, 16u), s);
-        if (atoi(e) == 12 && room(16u, 12u) <= cap) return launch_bvh_as<16, SGN, true, 12, RT_BVH_TAIL_LARGE>(a, room(16u, 12u), s);
+        if (atoi(e) == 8 && room(16u, 8u) <= cap) return launch_bvh_as<16, SGN, true, 8, RT_BVH_TAIL_LARGE>(a, room(16u, 8u), s);
         if (atoi(e) == 6 && room(16u, 6u) <= cap) return launch_bvh_as<16, SGN, true, 6, RT_BVH_TAIL_LARGE>(a, room(16u, 6u), s);
     }
 #endif
     if (room(16u, CAP) <= cap)     return launch_bvh_as<16, SGN, true, CAP, RT_BVH_TAIL_LARGE>(a, room(16u, CAP), s);
     if (room(16u, 6u) <= cap)      return launch_bvh_as<16, SGN, true, 6, RT_BVH_TAIL_LARGE>(a, room(16u, 6u), s);
-    return launch_bvh_as<8, SGN, false, CAP, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * ((size_t)CAP * 256u + 512u), s);
+    return launch_bvh_as<8, SGN, false, 8, RT_BVH_TAIL_LARGE>(a, 1024u + 8u * ((size_t)bvh_list_bytes(false, 8u) + 512u), s);
 }
 
 }  // namespace rtk
@@ -1017,14 +924,14 @@ hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s) {
     return a.signed_filter ? rtk::launch_bvh<true>(a, s) : rtk::launch_bvh<false>(a, s);
 }
 
-hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, float4* ball, hipStream_t s) {
+hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtk::bvh_refit, dim3((n_nodes + 3u) / 4u), dim3(256), 0, s, rec, link, n_nodes, records, ball);
+    hipLaunchKernelGGL(rtk::bvh_refit, dim3((n_nodes + 3u) / 4u), dim3(256), 0, s, rec, link, n_nodes, records);
     return hipGetLastError();
 }
 
-hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, float4* ball, const float* records, hipStream_t s) {
+hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtk::bvh_fill_leaves, dim3((n_nodes + 255u) / 256u), dim3(256), 0, s, rec, link, n_nodes, geo_f, ball, records);
+    hipLaunchKernelGGL(rtk::bvh_fill_leaves, dim3((n_nodes + 255u) / 256u), dim3(256), 0, s, rec, link, n_nodes, geo_f);
     return hipGetLastError();
 }

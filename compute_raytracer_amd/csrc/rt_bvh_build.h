@@ -27,8 +27,6 @@ struct Builder {
     std::vector<uint32_t>& out_link;
     std::vector<uint32_t> ids;
     uint32_t arity = 4;            // children per inner node at most (2..8)
-    std::vector<float>* out_ball = nullptr;   // optional: 4 floats per node, the plain bound {C, R sigma rounded up} of an inner node
-                                               // (leaves: zeros, filled on the device like their records)
 
     // NaN coordinates order as 0 (a sphere with a NaN in it can never be hit: every comparison of the
     // literal test is false), so that the sorts below keep a strict weak ordering on any input
@@ -43,7 +41,6 @@ struct Builder {
 
     void leaf(uint32_t sphere) {
         out_rec.insert(out_rec.end(), {0.0f, 0.0f, 0.0f, 0.0f});   // filled on the device from geo_f
-        if (out_ball) out_ball->insert(out_ball->end(), {0.0f, 0.0f, 0.0f, 0.0f});
         out_link.push_back(0x80000000u | sphere);
     }
 
@@ -105,7 +102,7 @@ struct Builder {
 
     // bounding sphere of ids[lo,hi): centre of the members' box, then shrink-wrapped -- the centre
     // moves towards the farthest member while that reduces the radius
-    void bound(uint32_t lo, uint32_t hi, float out[4], float ball[4]) {
+    void bound(uint32_t lo, uint32_t hi, float out[4]) {
         double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (uint32_t k = lo; k < hi; ++k)
             for (int a = 0; a < 3; ++a) {
@@ -161,26 +158,22 @@ struct Builder {
         const double k = c2 * (1.0 - (double)RT_FILTER_EPS) - R * R * (1.0 + (double)RT_FILTER_KAPPA);
         out[0] = C[0] * RT_FILTER_SCALE; out[1] = C[1] * RT_FILTER_SCALE; out[2] = C[2] * RT_FILTER_SCALE;
         out[3] = (float)(k * (double)RT_FILTER_SCALE2);
-        float Rf = (float)R;
-        if ((double)Rf < R) Rf = std::nextafter(Rf, INFINITY);
-        ball[0] = C[0]; ball[1] = C[1]; ball[2] = C[2]; ball[3] = Rf;
     }
 
     void emit(uint32_t lo, uint32_t hi) {
         if (hi - lo == 1u) { leaf(ids[lo]); return; }
         const size_t me = out_link.size();
         out_rec.insert(out_rec.end(), {0.0f, 0.0f, 0.0f, 0.0f});
-        if (out_ball) out_ball->insert(out_ball->end(), {0.0f, 0.0f, 0.0f, 0.0f});
         out_link.push_back(0u);
         children(lo, hi);
-        float b[4], ball[4];
-        bound(lo, hi, b, ball);
+        float b[4];
+        bound(lo, hi, b);
         std::copy(b, b + 4, out_rec.begin() + 4 * me);
-        if (out_ball) std::copy(ball, ball + 4, out_ball->begin() + 4 * me);
         out_link[me] = 4u * (uint32_t)out_link.size();  // skip link: first node after this subtree, as 4 * index
     }
 
-    // up to four children: the largest part is split until there are four
+    // up to `arity` children (four: C3 1.50 / 1.55 / 1.61 / 1.65 ms with 4 / 5 / 6 / 8, profiles/r04/bvh_arity_probe.log): the largest
+    // part is split until there are that many
     void children(uint32_t lo, uint32_t hi) {
         if (hi - lo <= arity) {
             for (uint32_t k = lo; k < hi; ++k) leaf(ids[k]);
@@ -208,14 +201,11 @@ struct Builder {
 // sphere) as leaves of their own -- inside a node they would inflate it to cover everything --,
 // then up to four subtrees over the rest.  Returns the node count n; the arrays hold n + 1
 // entries, the last one being the sentinel the traversal loop parks finished lanes on.
-inline uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4, std::vector<uint32_t>& link, uint32_t arity = 4u,
-                             std::vector<float>* ball = nullptr) {
+inline uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float>& rec4, std::vector<uint32_t>& link, uint32_t arity = 4u) {
     rec4.clear(); link.clear();
-    if (ball) ball->clear();
     if (n == 0) return 0;
     rec4.reserve((size_t)n * 6u); link.reserve((size_t)n * 3u / 2u + 8u);
     Builder b{records, rec4, link, {}};
-    b.out_ball = ball;
     b.arity = arity < 2u ? 2u : (arity > 8u ? 8u : arity);
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = 0; i < n; ++i)
@@ -234,7 +224,6 @@ inline uint32_t rt_bvh_build(const float* records, uint32_t n, std::vector<float
     if (!b.ids.empty()) b.children(0u, (uint32_t)b.ids.size());
     const uint32_t nodes = (uint32_t)link.size();
     rec4.insert(rec4.end(), {0.0f, 0.0f, 0.0f, INFINITY});   // sentinel [nodes]: never passes, links to itself
-    if (ball) ball->insert(ball->end(), {0.0f, 0.0f, 0.0f, -INFINITY});
     link.push_back(4u * nodes);
     return nodes;
 }

@@ -75,10 +75,8 @@ struct rt_ctx {
     // build result and its device copy
     std::vector<float> h_records;
     std::vector<float> h_bvh_rec;
-    std::vector<float> h_bvh_ball;            // plain bounds of the inner nodes (rt_bvh_build.h), 4 floats per node
     std::vector<uint32_t> h_bvh_link;
-    float4* d_bvh_rec = nullptr;              // [bvh_cap] records, then [bvh_cap] plain bounds (d_bvh_ball)
-    float4* d_bvh_ball = nullptr;
+    float4* d_bvh_rec = nullptr;
     uint32_t* d_bvh_link = nullptr;
     uint32_t bvh_cap = 0, bvh_nodes = 0;
     bool bvh_valid = false;              // the device records bound the current spheres

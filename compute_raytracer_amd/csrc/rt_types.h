@@ -70,7 +70,6 @@ struct RtFrameArgs {
     const float4* bvh_rec;     // [bvh_nodes] node records, same layout as geo_f (leaves ARE geo_f records)
     const uint32_t* bvh_link;  // [bvh_nodes] inner node: 4 * (index after its subtree); leaf: 0x80000000 | sphere
     uint32_t bvh_nodes;        // 0: no hierarchy built
-    const float4* bvh_ball;    // [bvh_nodes + 1] plain bounds {C, R sigma} of every node (the compact form is staged from them)
     uint32_t grid_share;       // >1: this frame's persistent grid takes 1/grid_share of the chip (frames in flight)
     uint32_t bvh_tail;         // lanes still walking below which a wave leaves the walk for the shading pass (0: never)
 };
@@ -105,7 +104,7 @@ hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
 hipError_t rt_launch_bvh(const RtFrameArgs& a, hipStream_t s);
 hipError_t rt_launch_sky_resolve(const RtFrameArgs& a, hipStream_t s);   // textured sky: composes the end-of-path records in a.fin (rt_bvh.hip)
-hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, float4* ball, hipStream_t s);
-hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, float4* ball, const float* records, hipStream_t s);
+hipError_t rt_launch_bvh_refit(float4* rec, const uint32_t* link, uint32_t n_nodes, const float* records, hipStream_t s);
+hipError_t rt_launch_bvh_fill(float4* rec, const uint32_t* link, uint32_t n_nodes, const float4* geo_f, hipStream_t s);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t W, uint32_t H,
                               uint32_t world, uint32_t padded_tiles, hipStream_t s);

@@ -66,8 +66,7 @@ typedef enum rt_kernel_id {
     RT_KID_TRIANGLES = 8,        /* trace_triangles (TLAS / BLAS traversal) */
     RT_KID_HEATMAP = 9,          /* heatmap_triangles */
     RT_KID_TRIANGLES_FLOW = 10,  /* trace_flow: persistent waves, one traversal step per trip, BLAS heads in LDS (rt_flow.hip) */
-    RT_KID_TRIANGLES_TILES = 11, /* trace_tiles: persistent waves, a tile per wave at a time, BLAS heads in LDS (rt_flow.hip) */
-    RT_KID_HIERARCHY_12C = 12    /* bvh_pixels, 12-wave workgroups, two per CU, 10-byte compact nodes (scenes whose 20-byte nodes leave room for one workgroup) */
+    RT_KID_TRIANGLES_TILES = 11  /* trace_tiles: persistent waves, a tile per wave at a time, BLAS heads in LDS (rt_flow.hip) */
 } rt_kernel_id;
 
 typedef enum rt_kernel {
@@ -320,10 +319,6 @@ int rt_group_wait(rt_group* g);
  * when cap_nodes < n_nodes + 1 (*n_nodes is set either way; at most 2 n + 64 nodes). */
 int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* link, uint32_t cap_nodes,
                        uint32_t* n_nodes);
-/* The same build, the plain bounds of its inner nodes: n_nodes + 1 entries {centre, radius (x 1.04, rounded up)} in the order of
- * rt_build_hierarchy's records -- what the compact form of the hierarchy kernel (RT_KID_HIERARCHY_12C: f16 centres, 10 bytes per
- * node) is staged from; leaf entries are zero here (the device writes a leaf's sphere), the sentinel's radius is -inf. */
-int rt_build_hierarchy_bounds(const float* records, uint32_t n, float* ball4, uint32_t cap_nodes, uint32_t* n_nodes);
 
 /* Runs the HOST side of the persistent triangle kernel on its own (no device, no context): the relinked copy of the BLAS
  * trees it walks.  `nodes`: the node buffer as rt_write_nodes receives it (8 f32 per node); `roots`: the

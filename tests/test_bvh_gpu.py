@@ -57,6 +57,21 @@ def test_degenerate_scenes(oracle):
         assert st["rays"] == rays, name
 
 
+@pytest.mark.parametrize("n", [14, 40, 130])
+def test_every_lane_fills_its_list_at_once(oracle, n):
+    """n spheres stacked on one centre, radii a hair apart, filling the view: every ray of a wave passes every leaf, all
+    sixty-four candidate lists fill in the same steps, and the pooled evaluation (trace_bvh: drain) has more entries than the
+    pool holds beside the unread rows -- the round that evaluates what is pooled and starts over runs, several times per walk
+    for the larger n.  The nearest hit is the outermost sphere, the shadow rays start inside the stack."""
+    spheres = [rt.Sphere([0.0, 1.0, -4.0], 2.5 + 0.003 * k, [0.2 + 0.6 * (k % 3 == 0), 0.5, 0.3 + 0.5 * (k % 2)]) for k in range(n)]
+    scene = rt.SceneRaytracing().createScene(spheres)
+    W, H, B = 96, 64, 3
+    ref, _, rays = oracle_render(oracle, scene, W, H, B)
+    img, st = gpu_render(scene, W, H, B, strict=False, variant=BVH)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays
+
+
 def test_zero_bounces_and_no_spheres(oracle):
     scene = rt.SceneRaytracing().createScene(synthetic_spheres(40, 11))
     ref, _, rays = oracle_render(oracle, scene, 64, 40, 0)

@@ -273,158 +273,3 @@ def test_reversed_shadow_walk_scales_and_offsets(seed):
     if seed == 4:
         light = np.array(spheres[3].center, float)            # the light inside a sphere
     run_shadow_case(spheres, light, seed, count=400)
-
-
-# ---- the compact form (RT_KID_HIERARCHY_12C): f16 centres, the node test about the node's own centre ----------------------
-# Staging and test restated from rt_bvh.hip (bvh_pixels<..., CMP>: the staging loop; trace_bvh: passes, CMP) in fp32 numpy:
-# v_fma_mix_f32 is one rounding of (f16 value x 2^-12 + c), the clamp maps NaN to 0, K sits in the upper half of a dword whose
-# lower half is cz's f16 pattern.  A leaf is a node with one member: the same obligations as above, every literally accepted
-# sphere is reached, for forward rays and for the reversed walk of shadow rays.
-CS, CS2 = f32(2.0 ** -12), f32(2.0 ** -24)
-
-
-def f32_up(v):
-    f = f32(v)
-    return f if float(f) >= v or v != v else np.nextafter(f, f32(np.inf))
-
-
-def compact_nodes(rec):
-    out, link, m = hierarchy(rec)
-    cap = 2 * rec.shape[0] + 64
-    ball = np.zeros((cap, 4), f32)
-    nodes = ctypes.c_uint32(0)
-    fp = ctypes.POINTER(ctypes.c_float)
-    assert abi.load().rt_build_hierarchy_bounds(rec.ctypes.data_as(fp), rec.shape[0], ball.ctypes.data_as(fp), cap, ctypes.byref(nodes)) == 0
-    assert nodes.value == m
-    ball = ball[: m + 1].copy()
-    for i in range(m):                              # bvh_fill_leaves
-        if link[i] & LEAF:
-            s = int(link[i] & 0x7FFFFFFF)
-            ball[i] = [rec[s, 0], rec[s, 1], rec[s, 2], f32_up(abs(float(rec[s, 7])) * 1.04)]
-    assert ball[m, 3] == -np.inf
-    with np.errstate(over="ignore", invalid="ignore"):
-        h16 = ball[:, 0:3].astype(np.float16)
-        back = h16.astype(f32)
-        wide = (np.abs(back) > 65504.0).any(axis=1)
-        back = np.where(np.abs(back) > 65504.0, f32(0), back)
-        small = ~(np.abs(back) >= f32(2.0 ** -14))
-        back = np.where(small, np.where(np.isnan(ball[:, 0:3]), ball[:, 0:3], f32(0)), back).astype(f32)
-        cbits = np.where(small | (np.abs(h16.astype(f32)) > 65504.0), np.float16(0), h16).astype(np.float16).view(np.uint16).astype(np.uint32)
-        diff = np.abs((back - ball[:, 0:3]).astype(f32))
-        e1 = ((diff[:, 0] + diff[:, 1]).astype(f32) + diff[:, 2]).astype(f32)
-        Rc = ((ball[:, 3] + (f32(1.0401) * e1).astype(f32)).astype(f32) * f32(1.000002)).astype(f32)
-        Ks = (Rc * CS).astype(f32)
-        K = ((Ks * Ks).astype(f32) * f32(1.000001)).astype(f32)
-        kh = (K.view(np.uint32).astype(np.uint64) + 0xFFFF) >> 16
-        kh = np.where((kh > 0x7F80) | wide, 0x7F80, kh)
-        kh = np.where(~(Rc >= 0), 0xFF80, kh).astype(np.uint32)
-    cz_k = ((kh << 16) | cbits[:, 2]).astype(np.uint32).view(f32)
-    centre = np.where(small | wide[:, None], f32(0), h16.astype(f32)).astype(f32)      # what v_fma_mix_f32 reads
-    return centre, cz_k, link, m, ball
-
-
-def mix(c16, nw):          # v_fma_mix_f32: f16 operand (held here as its f32 value) x 2^-12 + nw, one rounding
-    return f32(np.float64(c16) * np.float64(CS) + np.float64(nw))
-
-
-def walk_compact(centre, cz_k, link, m, o, d, madd=0.0):
-    o = o.astype(f32); d = d.astype(f32)
-    a = f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2]))
-    inv = f32(f32(1.0 / np.sqrt(np.float64(a))) * f32(1.0 + KAPPA_H))
-    h = (d * inv).astype(f32)
-    nw = (-(o * CS)).astype(f32)
-    negm = f32(-f32(madd) * CS2)
-    cands, tests, j = [], 0, 0
-    with np.errstate(over="ignore", invalid="ignore"):
-        while j != m:
-            c, k, lk = centre[j], cz_k[j], int(link[j])
-            ocx, ocy, ocz = mix(c[0], nw[0]), mix(c[1], nw[1]), mix(c[2], nw[2])
-            nb = fma(ocz, h[2], fma(ocy, h[1], f32(ocx * h[0])))
-            nb = f32(0.0) if not nb > 0 else min(nb, f32(1.0))                 # clamp (NaN -> 0)
-            q3 = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -k)))
-            passed = bool(fma(nb, nb, -q3) > negm)
-            leaf = bool(lk & LEAF)
-            if leaf and passed:
-                cands.append(lk & 0x7FFFFFFF)
-            j = j + 1 if (leaf or passed) else lk // 4
-            tests += 1
-    return set(cands), tests
-
-
-def run_compact_case(spheres, cam, light, seed, count=400):
-    rec = np.ascontiguousarray(rt.SceneRaytracing().createScene(spheres).pack_spheres(), dtype=f32).reshape(-1, 8)
-    centre, cz_k, link, m, ball = compact_nodes(rec)
-    out, _, _ = hierarchy(rec)
-    rng = np.random.default_rng(seed)
-    hits_n = tests_c = tests_e = 0
-    for o, d in rays_for(rec, cam, light, rng, count):
-        hits = literal_hits(rec, o, d)
-        cands, tests = walk_compact(centre, cz_k, link, m, o, d)
-        assert hits <= cands, ("lost", sorted(hits - cands), o, d)
-        hits_n += len(hits); tests_c += tests; tests_e += walk(out, link, m, o, d, True)[1]
-    return hits_n, tests_c, tests_e, rec.shape[0]
-
-
-def run_compact_shadow_case(spheres, light, seed, count):
-    rec = np.ascontiguousarray(rt.SceneRaytracing().createScene(spheres).pack_spheres(), dtype=f32).reshape(-1, 8)
-    centre, cz_k, link, m, ball = compact_nodes(rec)
-    L = np.array(light, f32)
-    n_lit = 0
-    for P in shaded_points(rec, L, np.random.default_rng(seed), count):
-        dl = (P - L).astype(f32)
-        s = (dl / length32(dl)).astype(f32)
-        if not np.isfinite(s).all():
-            continue
-        hit, t = literal_hits(rec, L, s, want_t=True)
-        wo, wd, madd = reversed_walk_ray(L, P, s)
-        cands, _ = walk_compact(centre, cz_k, link, m, wo, wd, madd)
-        keep = np.zeros_like(hit); keep[list(cands)] = True
-        want = lit(hit, t, L, s, P)
-        assert lit(hit & keep, t, L, s, P) == want, ("shadow result changed", P, L)
-        ell = np.linalg.norm((P - L).astype(np.float64))
-        d_a = 0.005001 + 10 * 2.0 ** -24 * (ell + np.linalg.norm(L.astype(np.float64)))
-        near = set(np.nonzero(hit & (t.astype(np.float64) < ell + d_a))[0].tolist())
-        assert near <= cands, ("lost", sorted(near - cands), P, L)
-        n_lit += want
-    return n_lit
-
-
-def test_compact_form_baseline_scene_rays():
-    hits, tests_c, tests_e, n = run_compact_case(synthetic_spheres(300, 5), [0.0593, 2.692, 3.293], [0, 5, 0], seed=1, count=600)
-    assert hits > 300
-    assert tests_c < 1.1 * tests_e            # f16 centres and the leaves' 4 % cost a few tests, not the walk
-
-
-@pytest.mark.parametrize("seed", range(6))
-def test_compact_form_scales_and_offsets(seed):
-    """Scenes of the sign-aware form (reach < 342): the only ones the compact form takes."""
-    rng = np.random.default_rng(300 + seed)
-    scale = float(10 ** rng.uniform(-2, 1.7))
-    off = float(rng.choice([0.0, 10.0, 100.0])) * np.array([1.0, 0.5, -0.25])
-    ratio = float(10 ** rng.uniform(0, 2.5))
-    n = int(rng.choice([17, 64, 200]))
-    spheres = [rt.Sphere(off + rng.normal(size=3) * scale, scale * 0.25 / ratio * float(10 ** rng.uniform(0, np.log10(ratio))),
-                         [1, 1, 1]) for _ in range(n)]
-    if seed % 2:
-        R = scale * float(10 ** rng.uniform(0.5, 1.0))
-        spheres.append(rt.Sphere(off + np.array([0, -R - scale, 0]), R, [1, 1, 1]))
-    cam = off + np.array([0.0, 0.5 * scale, 3.0 * scale])
-    light = off + np.array([0.3 * scale, 2.5 * scale, 0.5 * scale])
-    hits, _, _, _ = run_compact_case(spheres, cam, light, seed, count=300)
-    assert hits > 0
-    run_compact_shadow_case(spheres, light, seed, count=300)
-
-
-def test_compact_form_reversed_shadow_walk_baseline_scene():
-    assert run_compact_shadow_case(synthetic_spheres(300, 5), [0, 5, 0], seed=1, count=900) > 50
-
-
-def test_compact_form_tiny_and_far_centres():
-    """Centres below f16's normal range become 0, radii carry the difference; spheres far from the origin lose three digits
-    of their centre and get it back as radius."""
-    rng = np.random.default_rng(11)
-    spheres = [rt.Sphere(rng.normal(size=3) * 1e-5, 0.01 * float(rng.uniform(0.5, 2)), [1, 1, 1]) for _ in range(40)]
-    spheres += [rt.Sphere(np.array([200.0, 100.0, -150.0]) + rng.normal(size=3), 0.05 * float(rng.uniform(0.5, 2)), [1, 1, 1]) for _ in range(60)]
-    hits, _, _, _ = run_compact_case(spheres, [0.0, 0.02, 0.1], [150.0, 120.0, -100.0], seed=5, count=400)
-    assert hits > 0
-    run_compact_shadow_case(spheres, [150.0, 120.0, -100.0], seed=6, count=300)
