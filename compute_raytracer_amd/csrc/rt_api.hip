@@ -922,7 +922,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.n_blas_lookup = c->inst.lookup_on ? (uint32_t)c->inst.lookup.size() : (uint32_t)(c->d_blas_lookup[v].used / 4u);
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
-        ts.tile_order = nullptr; ts.tile_cost = nullptr;
+        ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u;
         ts.pairs = (have_pairs && ts.n_blas <= 12u) ? static_cast<const float4*>(c->d_flow.p) : nullptr;
         for (uint32_t i = 0; i < 12u; ++i) ts.root_meta[i] = fl.root_meta[i];
 #ifdef RT355_DEV_EXPORTS
@@ -931,6 +931,9 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         if (order_set >= 0) {
             ts.tile_cost = static_cast<uint32_t*>(c->d_tile_cost[order_set].p);
             if (c->order_tiles[order_set] == order_n) ts.tile_order = static_cast<const uint32_t*>(c->d_tile_order[order_set].p);
+#ifdef RT355_DEV_EXPORTS
+            if (getenv("RT355_TRI_NOLIST")) ts.tile_order = nullptr;
+#endif
         }
         if (use_flow) {
             // One 16-wave workgroup per CU when the frame has the chip to itself -- all the LDS the stacks leave goes to pair

@@ -21,6 +21,7 @@ struct RtTriScene {
     uint32_t root_meta[12];    // instances the tile kernel stages (rt_tri_device.h: kLdsBlas)
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    uint32_t xcd_rows;         // set by the launch (no work list): workgroup b renders row (b % 8) + 8 (b / 8 / tiles per row) -- a row per XCD
 };
 
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);

@@ -60,6 +60,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
         else if ((i -= 16u * s16) < 4u * s4) { tile = list[s16 + (i >> 2)]; part = i & 3u; }
         else if ((i -= 4u * s4) < n_tiles - s16 - s4) tile = list[s16 + s4 + i];
         else return;                                                        // the grid is sized for the most parts there can be
+    } else if (T.xcd_rows != 0u) {
+        // Workgroups go to the eight XCDs in turn (b % 8) and each XCD has an L2 of its own: in index order every XCD renders
+        // every eighth tile of every row and its L2 holds what the whole band of rows in flight touches.  Here XCD x renders rows
+        // x, x + 8, ... left to right: the tiles it holds at any time are neighbours (the grid is padded to eight rows).
+        const uint32_t k = blockIdx.x >> 3;
+        const uint32_t r = (blockIdx.x & 7u) + 8u * (k / groups_x);
+        if (r >= A.n_local_tiles) return;
+        tile = r * groups_x + (k - (k / groups_x) * groups_x);
     }
     const uint32_t by = tile / groups_x, bx = tile - by * groups_x;
     if ((part < 4u && lane >= 16u) || (part >= 16u && lane >= 4u)) return;
@@ -236,10 +244,16 @@ hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* loo
 // (1 / 2 / 4 / 8 waves: 0.545 / 0.571 / 0.603 / 0.624 ms for the 1344x846 frame one at a time, 0.769 / 0.765 /
 // 0.792 / 0.883 ms per 4K frame in flight; profiles/r02/tri_waves.log).
 template <typename STK, int OCC, bool PACKED, int WAVES = 1, bool PAIRS = false>
-static void launch_tri(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
+static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, hipStream_t s) {
     const dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
     const uint32_t n_tiles = grid.x * grid.y;       // trace_triangles decodes the tile itself; with a work list: room for the quarters
-    const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) + 15u * std::min(n_tiles / 64u, 256u) : n_tiles, 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
+    RtTriScene t = t0;
+    t.xcd_rows = (!t.tile_order && !heatmap) ? 1u : 0u;
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_XCD")) t.xcd_rows = t.xcd_rows && atoi(e) != 0;
+#endif
+    const uint32_t padded = grid.x * ((grid.y + 7u) & ~7u);
+    const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) + 15u * std::min(n_tiles / 64u, 256u) : (t.xcd_rows ? padded : n_tiles), 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
     if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK, PACKED>), grid, dim3(64 * WAVES), 0, s, a, t);
     else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED, PAIRS>), line, dim3(64 * WAVES), 0, s, a, t);
     else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED, PAIRS>), line, dim3(64 * WAVES), 0, s, a, t);
