@@ -295,7 +295,8 @@ __device__ __forceinline__ void reversed_shadow_walk(bool shadow, v3 L, float li
 }
 
 // Advances the walk of every lane's ray (o, d).  R/L: node records and links (LDS or global),
-// n: node count, geo: exact {c, r*r}.  slot: this lane's candidate column ([k*64]).
+// n: node count, geo: exact {c, r*r}.  slot: this lane's candidate column (nodes in LDS: two-byte entries, 128 bytes
+// apart; nodes in global memory: four-byte entries, [k*64]).
 // i: the lane's position in the node array, in and out: 0 starts a ray (the caller then also sets
 // nearest = 9999, idx = -1, RK:172), n = no ray / walk complete.  TAIL > 0: once some lanes have
 // completed and fewer than TAIL lanes are still walking, the call returns; the stragglers resume
@@ -329,7 +330,7 @@ __device__ __forceinline__ void trace_bvh(const uint32_t tail, const float4* __r
     const v3 hs = V(h.x * kT, h.y * kT, h.z * kT);
     const v3 ms = V(m.x * kT2, m.y * kT2, m.z * kT2);
     const float ps = -p * kT, qs = q * kT2;
-    // this lane's candidate column in LDS: entries 256 bytes apart; wa = LDS address of the next free one
+    // this lane's candidate column in LDS: entries 128 (two-byte, L16 below) or 256 bytes apart; wa = LDS address of the next free one
     typedef __attribute__((address_space(3))) uint32_t* lds_u32_w;
     typedef __attribute__((address_space(3))) uint16_t* lds_u16_w;
     const uint32_t wa0 = (uint32_t)(uintptr_t)slot;
