@@ -100,6 +100,20 @@ def test_mid_size_scenes_take_the_twelve_wave_form(oracle, n):
     assert st["rays"] == rays
 
 
+@pytest.mark.parametrize("n,kernel", [(1900, "hierarchy_12"), (4700, "hierarchy_16")])
+def test_scenes_at_the_edge_of_a_form_keep_six_entry_lists(oracle, n, kernel):
+    """Just before a form's LDS runs out its candidate lists shrink from twelve entries per lane to six (rt_bvh.hip: launch_bvh):
+    1900 spheres are the last the two 12-wave workgroups take, 4700 the last of the one 16-wave workgroup."""
+    scene = rt.SceneRaytracing().createScene(synthetic_spheres(n, 43))
+    W, H, B = 168, 104, 4
+    ref, _, rays = oracle_render(oracle, scene, W, H, B)
+    img, st = gpu_render(scene, W, H, B, strict=False, variant=BVH)
+    assert np.array_equal(img, ref), diff_stats(img, ref)
+    assert st["rays"] == rays
+    from compute_raytracer_amd import abi
+    assert abi.KERNEL_IDS[st["kernel_id"]] == kernel
+
+
 def test_partitioned_ranks_reassemble(oracle):
     scene = rt.SceneRaytracing().createScene(synthetic_spheres(300, 5))
     W, H, B, world = 200, 123, 4, 3
