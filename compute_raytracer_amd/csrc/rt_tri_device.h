@@ -130,10 +130,16 @@ __device__ __forceinline__ bool hit_triangle(const RtTriScene& T, uint32_t slot,
 // PAIRS (with PACKED, and every instance staged): the walk reads the library's relinked pair records (rt_flow_build.h) -- one
 // 64-byte record per inner node, metas packed when the copy was built: no u32(f32) per node, no packing at a push, and the
 // root's meta comes with the staged instance record instead of a node load.  Same boxes, same order, same decisions.
-template <bool COUNT, typename STK, bool PACKED, bool PAIRS = false>
+// P16 (with PAIRS, scenes whose leaves hold at most three triangles and whose pair records and lookup slots number at most
+// 16,384 -- what the reference's builder makes of meshes up to that size): a stack entry is (count << 14 | x) in TWO bytes;
+// both stacks, the staged heads and the instance records then take 7,616 bytes of LDS per wave and a fifth wave per SIMD fits.
+template <bool COUNT, typename STK, bool PACKED, bool PAIRS = false, bool P16 = false>
 __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L, uint32_t bi, v3 o, v3 d, float& nearest,
-                                           TriHit& hit, typename std::conditional<PACKED, uint32_t, STK>::type* stack,
+                                           TriHit& hit, typename std::conditional<PACKED && !P16, uint32_t, STK>::type* stack,
                                            uint32_t stride, float& traces) {
+    typedef typename std::conditional<PACKED && !P16, uint32_t, STK>::type BSTK;
+    auto pack16 = [](uint32_t m) -> uint32_t { return ((m >> 16) << 14) | (m & 0x3FFFu); };
+    auto unpack16 = [](uint32_t e) -> uint32_t { return ((e >> 14) << 16) | (e & 0x3FFFu); };
     float m[17];                                                    // mat4 column-major, m[4c + r]; m[16] root index
     if (bi < L.n_blas) {
 #pragma unroll
@@ -171,11 +177,11 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
                 if (d1 > pNearest) {                                // RK:292
                     if (psp == 0u) break;
                     psp -= 1u;
-                    pnode = stack[sclamp(psp) * stride];            // RK:297-298
+                    pnode = P16 ? unpack16(stack[sclamp(psp) * stride]) : (uint32_t)stack[sclamp(psp) * stride];   // RK:297-298
                 } else {
                     pnode = swap ? m2 : m1;                         // RK:302
                     if (d2 < pNearest) {                            // RK:303-304 (no overflow guard upstream)
-                        stack[sclamp(psp) * stride] = swap ? m1 : m2;
+                        stack[sclamp(psp) * stride] = (BSTK)(P16 ? pack16(swap ? m1 : m2) : (swap ? m1 : m2));
                         psp += 1u;
                     }
                 }
@@ -192,7 +198,7 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
                 }
                 if (psp == 0u) break;                               // RK:324
                 psp -= 1u;
-                pnode = stack[sclamp(psp) * stride];                // RK:328-329
+                pnode = P16 ? unpack16(stack[sclamp(psp) * stride]) : (uint32_t)stack[sclamp(psp) * stride];       // RK:328-329
             }
         }
         nearest = pNearest < nearest ? pNearest : nearest;          // RK:227-229
@@ -255,9 +261,9 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
 }
 
 // RK:168-244 traceTLAS.  tstack / bstack: this lane's two LDS stacks.
-template <bool COUNT, typename STK, bool PACKED, bool PAIRS = false>
+template <bool COUNT, typename STK, bool PACKED, bool PAIRS = false, bool P16 = false>
 __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& L, v3 o, v3 d, STK* tstack,
-                                             typename std::conditional<PACKED, uint32_t, STK>::type* bstack, uint32_t stride, float& traces) {
+                                             typename std::conditional<PACKED && !P16, uint32_t, STK>::type* bstack, uint32_t stride, float& traces) {
     TriHit hit; hit.t = 0.0f; hit.u = hit.v = 0.0f; hit.tri = -1; hit.blas = -1;   // RK:170-171
     float nearest = 9999.0f;                                        // RK:172
     const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -293,7 +299,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
                 if (li >= T.n_blas_lookup) li = T.n_blas_lookup - 1u;
                 uint32_t bi = u32f(li < L.n_lookup ? L.blas[20u * li + 19u] : T.blas_lookup[li]);   // RK:223
                 if (bi >= T.n_blas) bi = T.n_blas - 1u;
-                trace_blas<COUNT, STK, PACKED, PAIRS>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
+                trace_blas<COUNT, STK, PACKED, PAIRS, P16>(T, L, bi, o, d, nearest, hit, bstack, stride, traces);   // RK:221-230
             }
             if (sp == 0u) break;                                    // RK:233
             sp -= 1u;

@@ -32,9 +32,9 @@ namespace rtk {
 
 // ---- kernel: RK main over the triangle scene ---------------------------------------------------------
 // FLAT: compiled for a one-colour 1x1 sky (A.sky_flat) -- no cube filtering code inside the traversal's register budget.
-template <int WAVES, typename STK, int OCC, bool FLAT, bool PACKED, bool PAIRS = false>
+template <int WAVES, typename STK, int OCC, bool FLAT, bool PACKED, bool PAIRS = false, bool P16 = false>
 __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
-    typedef typename std::conditional<PACKED, uint32_t, STK>::type BSTK;
+    typedef typename std::conditional<PACKED && !P16, uint32_t, STK>::type BSTK;
     __shared__ STK tstacks[kStack * 64 * WAVES];
     __shared__ BSTK bstacks[kStack * 64 * WAVES];
     STK* tstack = tstacks + threadIdx.x;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     v3 ro = sc.cameraPos, rd = primary_dir(A, sc, x, y);
     float affect = 1.0f, sum = 0.0f;
     for (uint32_t bounce = 0; bounce < sc.bounces; ++bounce) {                       // RK:113
-        const TriHit h = trace_tlas<false, STK, PACKED, PAIRS>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
+        const TriHit h = trace_tlas<false, STK, PACKED, PAIRS, P16>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
         ++nrays;
         const bool hit = h.tri >= 0;
         if (bounce == 0) dist = hit ? h.t : 0.0f;                                    // RK:116-118
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
         // RK:146-166
         const v3 sdir = normalize(sub(ro, sc.lightPos));
         const float distance = length(sdir);
-        const TriHit sh = trace_tlas<false, STK, PACKED, PAIRS>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
+        const TriHit sh = trace_tlas<false, STK, PACKED, PAIRS, P16>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
         ++nrays;
         const float intensity = light_term(sc, ro, normal, sdir, distance, sh.tri >= 0, sh.t);
         const Albedo s = hit_albedo(T, tri, hu, hv);
@@ -243,7 +243,7 @@ hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* loo
 // WAVES: one wave per workgroup -- a workgroup's LDS and wave slots come free as soon as its own tile is done
 // (1 / 2 / 4 / 8 waves: 0.545 / 0.571 / 0.603 / 0.624 ms for the 1344x846 frame one at a time, 0.769 / 0.765 /
 // 0.792 / 0.883 ms per 4K frame in flight; profiles/r02/tri_waves.log).
-template <typename STK, int OCC, bool PACKED, int WAVES = 1, bool PAIRS = false>
+template <typename STK, int OCC, bool PACKED, int WAVES = 1, bool PAIRS = false, bool P16 = false>
 static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, hipStream_t s) {
     const dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
     const uint32_t n_tiles = grid.x * grid.y;       // trace_triangles decodes the tile itself; with a work list: room for the quarters
@@ -255,8 +255,8 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, 
     const uint32_t padded = grid.x * ((grid.y + 7u) & ~7u);
     const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) + 15u * std::min(n_tiles / 64u, 256u) : (t.xcd_rows ? padded : n_tiles), 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
     if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK, PACKED>), grid, dim3(64 * WAVES), 0, s, a, t);
-    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED, PAIRS>), line, dim3(64 * WAVES), 0, s, a, t);
-    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED, PAIRS>), line, dim3(64 * WAVES), 0, s, a, t);
+    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED, PAIRS, P16>), line, dim3(64 * WAVES), 0, s, a, t);
+    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED, PAIRS, P16>), line, dim3(64 * WAVES), 0, s, a, t);
 }
 
 hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
@@ -277,7 +277,12 @@ hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int he
     if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
     g_rt_kernel_id = heatmap ? RT_KID_HEATMAP : RT_KID_TRIANGLES;
     // the relinked pair records (rt_api.hip provides them when the scene fits: every instance staged, 16-bit fields)
-    if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas) launch_tri<uint16_t, 4, true, 1, true>(a, t, heatmap, s);
+    bool p16 = t.p16_ok != 0u;
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_P16")) p16 = p16 && atoi(e) != 0;
+#endif
+    if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16) launch_tri<uint16_t, 5, true, 1, true, true>(a, t, heatmap, s);
+    else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas) launch_tri<uint16_t, 4, true, 1, true>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u && t.packed_ok) launch_tri<uint16_t, 4, true>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u)           launch_tri<uint16_t, 4, false>(a, t, heatmap, s);
     else                                    launch_tri<uint32_t, 3, false>(a, t, heatmap, s);      // 44 KB of stacks: three workgroups per CU

@@ -307,6 +307,50 @@ def test_stack_depth_beyond_the_lds_slots_and_beyond_the_reference_stack(oracle,
     assert st["rays"] == rays and abi.KERNEL_IDS[st["kernel_id"]] == KERNELS[variant]
 
 
+@pytest.mark.parametrize("per_leaf", [3, 4, 7])
+def test_leaves_of_more_triangles_than_a_two_byte_stack_entry_counts(oracle, per_leaf):
+    """The five-waves-per-SIMD form of the tile kernel keeps (count << 14 | x) in two bytes per stack entry: leaves of at most
+    three triangles (the reference's builder stops at two).  A hand-made tree with three per leaf still takes it, four and seven
+    per leaf take the four-byte entries (rt_api.hip: p16_ok); same frame either way."""
+    depth = 9                                                    # spine_scene's tree with `per_leaf` triangles in every leaf, side by side
+    nodes = np.zeros((1 + 2 * depth, 8), np.float32)
+    tris = np.zeros(((depth + 1) * per_leaf, 40), np.float32)
+    def box(i, lo, hi, left, count):
+        nodes[i, 0:3] = lo; nodes[i, 3] = left; nodes[i, 4:7] = hi; nodes[i, 7] = count
+    box(0, [-9, -9, -1.0], [9, 9, 5.0], 2, 0)
+    for k in range(depth):
+        a, sidx = 1 + 2 * k, 2 + 2 * k
+        box(a, [-9, -9, -3.0], [9, 9, -2.0], k * per_leaf, per_leaf)
+        if k + 1 < depth: box(sidx, [-9, -9, -1.0], [9, 9, 5.0], 1 + sidx + 1, 0)
+        else: box(sidx, [-9, -9, -1.0], [9, 9, 5.0], depth * per_leaf, per_leaf)
+    for k in range(depth + 1):
+        for j in range(per_leaf):
+            z = (-2.05 - 0.9 * k / depth if k < depth else -0.5) - 0.01 * j
+            x0 = -8.0 + 16.0 * ((k * 7) % (depth + 1)) / (depth + 1) + 0.7 * j
+            w = 2.0 if k < depth else 30.0
+            t = k * per_leaf + j
+            for c, (x, y) in enumerate([(x0, -8.0), (x0 + w, -8.0), (x0 + w / 2, 9.0)]):
+                tris[t, 12 * c:12 * c + 3] = [x, y, z]
+                tris[t, 12 * c + 4:12 * c + 7] = [0, 0, 1]
+                tris[t, 12 * c + 8:12 * c + 10] = [c / 2.0, c % 2]
+            tris[t, 36:40] = [0.2 + 0.8 * ((t * 5) % 7) / 7.0, 0.3 + 0.7 * ((t * 3) % 5) / 5.0, 0.9 - 0.6 * (t % 4) / 4.0, 1.0 if t % 3 else 0.5]
+    dd = dict(triangles=tris, blas_nodes=nodes, tri_lookup=np.arange(tris.shape[0], dtype=np.float32),
+              mesh_root=np.array([1]), mesh_box_lo=np.array([[-9.0, -9.0, -3.0]]), mesh_box_hi=np.array([[9.0, 9.0, 5.0]]),
+              inst_mesh=np.array([0]), inst_position=np.array([[0.0, 0.0, 0.0]]), inst_eulers=np.array([[0.0, 0.0, 0.0]]),
+              inst_speed=np.array([[0.0, 0.0, 0.0]]), camera_position=np.array([0.0593, 2.692, 3.293]),
+              camera_eulers=np.array([0.0, 106.0, 270.0], np.float32), light=np.array([0.0, 5.0, 6.0, 3.0, 0.3]))
+    scene = rt.SceneRaytracing.from_packed(dd)
+    mat = rt.Material(np.random.default_rng(per_leaf).integers(0, 256, (8, 8, 4), dtype=np.uint8))
+    sky = random_sky(per_leaf)
+    W, H, B = 160, 96, 3
+    ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
+    assert len(np.unique(ref.reshape(-1, 4), axis=0)) > 20
+    for variant in (0, 6):
+        img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky, variant=variant)
+        assert np.array_equal(img, ref), (variant, diff_stats(img, ref))
+        assert st["rays"] == rays
+
+
 @pytest.mark.parametrize("variant", [0, 7, 8])
 def test_an_instance_that_changes_its_mesh_rebuilds_the_relinked_copy(oracle, variant):
     """The library's relinked copy of the BLAS trees is built from the roots the instance records name.  The reference rewrites
