@@ -900,7 +900,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
                 RT_HIP(hipMalloc(&b->p, (size_t)order_n * 4u + 8u));       // the list carries two header words
                 b->cap = (size_t)order_n * 4u;
             }
-            RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));   // tiles ADD their times
+            RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));   // tiles leave their times by atomicMax
             c->order_tiles[order_set] = 0;
         }
     }

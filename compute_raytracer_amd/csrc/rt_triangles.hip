@@ -121,7 +121,17 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     reinterpret_cast<uint32_t*>(A.out)[opix] =
         compose_pixel_sky(scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, primary_dir(A, sc, x, y))), color, dist);   // RK:91-98
     count_rays(A.rays, nrays);
-    if (T.tile_cost && threadIdx.x == 0u) atomicAdd(&T.tile_cost[tile], (uint32_t)(wall_clock64() - clk0));   // 10 ns ticks; quarters add up
+    // What a tile leaves for the next frame's work list (10 ns ticks) must not depend on how it was rendered, or the list chases
+    // its own tail: a whole tile leaves its time; the parts of a split tile leave the LONGEST of theirs, times what a wave of 64
+    // diverging lanes takes longer than its slowest sixteenth (3) or quarter (1.5) alone.  Summed, a split tile looked several times
+    // as long as it is and kept its place in the head of the list whatever the other tiles did: the four streams' lists settled in
+    // different selections (the reference's scene one frame at a time: 0.43 and 0.49 ms alternating with the streams); the plain
+    // maximum made it look short, and every list alternated between splitting a tile and not (0.45 / 0.55).  With the factors:
+    // 0.385-0.395 ms, every frame, every stream (profiles/r04/tri_cost_series.log).
+    if (T.tile_cost && threadIdx.x == 0u) {
+        const uint32_t dt = (uint32_t)(wall_clock64() - clk0);
+        atomicMax(&T.tile_cost[tile], part >= 16u ? 3u * dt : (part < 4u ? dt + (dt >> 1) : dt));
+    }
 }
 
 // ---- the order of the next frame's tiles ------------------------------------------------------------------
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
 // starts them in index order.  Measured with the kernel's own clock (tools/tile_cost_probe.py, profiles/r03/tile_cost.log):
 // mean tile 21 us, one in a hundred 156 us, the longest 498 us -- and the 1344x846 frame rendered on its own (the
 // reference's await-each-frame loop) took 504 us: a frame is as long as its longest tile, however empty the chip.  So
-//   * every tile leaves the time it took (tile_cost; quarters add theirs up);
+//   * every tile leaves the time it took (tile_cost; the parts of a split tile: the longest of theirs, scaled -- see the kernel's last lines);
 //   * one workgroup turns the costs into the NEXT frame's work list on the same stream: tiles longest first (a counting sort
 //     over quarter-octave classes), and the tiles longer than half the frame's throughput time -- sum of all costs / wave
 //     slots / 2 --, at most one in sixteen and 1024 (a quarter-wave for every wave slot of the chip), as four 4x4 quarters each: a quarter of the lanes diverge a quarter as much, and
