@@ -923,7 +923,10 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
         ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u;
-        ts.p16_ok = (have_pairs && c->node_count_max <= 3u && c->flow.n_pairs <= 16384u && ts.n_tri_lookup <= 16384u) ? 1u : 0u;
+        // two-byte stack entries (count << 14 | x): every meta of the records and of this frame's roots must fit them
+        ts.p16_ok = (have_pairs && c->flow.max_count <= 3u && c->flow.max_x <= 16383u) ? 1u : 0u;
+        for (uint32_t i = 0; i < 12u && ts.p16_ok; ++i)
+            if ((fl.root_meta[i] >> 16) > 3u || (fl.root_meta[i] & 0xFFFFu) > 16383u) ts.p16_ok = 0u;
         ts.pairs = (have_pairs && ts.n_blas <= 12u) ? static_cast<const float4*>(c->d_flow.p) : nullptr;
         for (uint32_t i = 0; i < 12u; ++i) ts.root_meta[i] = fl.root_meta[i];
 #ifdef RT355_DEV_EXPORTS

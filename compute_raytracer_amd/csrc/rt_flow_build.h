@@ -33,6 +33,8 @@ struct RtFlow {
     uint32_t n_nodes = 0;
     uint32_t min_node = 0xFFFFFFFFu;     // smallest node index the build read: a later write at or above it invalidates the copy
     bool ok = false;                     // false: the scene does not fit the 16-bit fields (the caller keeps the node walk)
+    uint32_t max_count = 0, max_x = 0;   // largest count and x field of any meta in the records: (count << 14 | x) fits two bytes
+                                         // while max_count <= 3 and max_x <= 16383 (the tile kernel's two-byte stack entries)
 };
 
 inline uint32_t rt_flow_u32f(float f) {                    // WGSL u32(f32): truncating, saturating, NaN -> 0
@@ -107,6 +109,8 @@ inline void rt_flow_build(const float* nodes, uint32_t n_nodes, const uint32_t* 
             const float* p = nodes + 8u * (size_t)child[c];
             if (rt_flow_u32f(p[7]) > 65535u) return;              // a count beyond 16 bits: not ok
             const uint32_t meta = rt_flow_meta(nodes, n_nodes, child[c], out.pair_of);
+            out.max_count = std::max(out.max_count, meta >> 16);
+            out.max_x = std::max(out.max_x, meta & 0xFFFFu);
             q[8 * c + 0] = p[0]; q[8 * c + 1] = p[1]; q[8 * c + 2] = p[2];
             std::memcpy(&q[8 * c + 3], &meta, 4);
             q[8 * c + 4] = p[4]; q[8 * c + 5] = p[5]; q[8 * c + 6] = p[6];

@@ -307,11 +307,13 @@ def test_stack_depth_beyond_the_lds_slots_and_beyond_the_reference_stack(oracle,
     assert st["rays"] == rays and abi.KERNEL_IDS[st["kernel_id"]] == KERNELS[variant]
 
 
-@pytest.mark.parametrize("per_leaf", [3, 4, 7])
+@pytest.mark.parametrize("per_leaf", [3, 4, 7, -3])
 def test_leaves_of_more_triangles_than_a_two_byte_stack_entry_counts(oracle, per_leaf):
     """The five-waves-per-SIMD form of the tile kernel keeps (count << 14 | x) in two bytes per stack entry: leaves of at most
     three triangles (the reference's builder stops at two).  A hand-made tree with three per leaf still takes it, four and seven
     per leaf take the four-byte entries (rt_api.hip: p16_ok); same frame either way."""
+    wild = per_leaf < 0                                          # -3: three per leaf, and one leaf whose first slot lies far beyond the lookup
+    per_leaf = abs(per_leaf)                                     # table (the oracle clamps it to the last slot; 14 bits would wrap it)
     depth = 9                                                    # spine_scene's tree with `per_leaf` triangles in every leaf, side by side
     nodes = np.zeros((1 + 2 * depth, 8), np.float32)
     tris = np.zeros(((depth + 1) * per_leaf, 40), np.float32)
@@ -334,6 +336,8 @@ def test_leaves_of_more_triangles_than_a_two_byte_stack_entry_counts(oracle, per
                 tris[t, 12 * c + 4:12 * c + 7] = [0, 0, 1]
                 tris[t, 12 * c + 8:12 * c + 10] = [c / 2.0, c % 2]
             tris[t, 36:40] = [0.2 + 0.8 * ((t * 5) % 7) / 7.0, 0.3 + 0.7 * ((t * 3) % 5) / 5.0, 0.9 - 0.6 * (t % 4) / 4.0, 1.0 if t % 3 else 0.5]
+    if wild:
+        nodes[5, 3] = 30000.0
     dd = dict(triangles=tris, blas_nodes=nodes, tri_lookup=np.arange(tris.shape[0], dtype=np.float32),
               mesh_root=np.array([1]), mesh_box_lo=np.array([[-9.0, -9.0, -3.0]]), mesh_box_hi=np.array([[9.0, 9.0, 5.0]]),
               inst_mesh=np.array([0]), inst_position=np.array([[0.0, 0.0, 0.0]]), inst_eulers=np.array([[0.0, 0.0, 0.0]]),
