@@ -95,22 +95,24 @@ def invert_mat4(mats):
     return np.where(ok[:, None], out, ident[None, :]).astype(F32)
 
 
+_HI = np.array([[(c >> 2) & 1, (c >> 1) & 1, c & 1] for c in range(8)], dtype=bool)      # corner c takes hi where its bit is set (x: 4, y: 2, z: 1)
+
+
 def world_boxes(mats, box_lo, box_hi):
     """(M, 3) f64 lo, hi (f32 values) and (M, 3) f32 centres of the instances' boxes.
-    box_lo / box_hi: (M, 3), the tree-level box of each instance's mesh."""
+    box_lo / box_hi: (M, 3), the tree-level box of each instance's mesh.  All eight corners of all instances at once; every
+    value goes through the operations of the corner-by-corner form in its order (products and sums left to right in f64, the
+    division, one rounding to f32)."""
     M = np.asarray(mats, dtype=np.float64)
-    lo = np.full((len(M), 3), 1e30)
-    hi = np.full((len(M), 3), -1e30)
-    for corner in range(8):
-        p = np.stack([np.where(corner & 4, box_hi[:, 0], box_lo[:, 0]),
-                      np.where(corner & 2, box_hi[:, 1], box_lo[:, 1]),
-                      np.where(corner & 1, box_hi[:, 2], box_lo[:, 2])], axis=1)
-        w = M[:, 3] * p[:, 0] + M[:, 7] * p[:, 1] + M[:, 11] * p[:, 2] + M[:, 15]
-        w = np.where((w == 0) | np.isnan(w), 1.0, w)               # `w = w || 1.0`: 0 and NaN are both falsy
-        q = np.stack([(M[:, k] * p[:, 0] + M[:, 4 + k] * p[:, 1] + M[:, 8 + k] * p[:, 2] + M[:, 12 + k]) / w
-                      for k in range(3)], axis=1).astype(F32).astype(np.float64)
-        lo = np.minimum(lo, q)
-        hi = np.maximum(hi, q)
+    p = np.where(_HI[None, :, :], np.asarray(box_hi)[:, None, :], np.asarray(box_lo)[:, None, :])      # (M, 8, 3)
+    px, py, pz = p[:, :, 0], p[:, :, 1], p[:, :, 2]
+    col = lambda i: M[:, i, None]
+    w = col(3) * px + col(7) * py + col(11) * pz + col(15)
+    w = np.where((w == 0) | np.isnan(w), 1.0, w)                   # `w = w || 1.0`: 0 and NaN are both falsy
+    q = np.stack([(col(k) * px + col(4 + k) * py + col(8 + k) * pz + col(12 + k)) / w for k in range(3)], axis=2)
+    q = q.astype(F32).astype(np.float64)                           # (M, 8, 3)
+    lo = np.minimum(1e30, q.min(axis=1))
+    hi = np.maximum(-1e30, q.max(axis=1))
     centre = ((lo + hi).astype(F32).astype(np.float64) / 2.0).astype(F32)
     return lo, hi, centre
 
