@@ -1006,9 +1006,19 @@ int rt_render(rt_ctx* c) {
     // back to back overlap on the device; rt_read_pixels returns the latest one
     const uint32_t k = c->frames_rendered % (uint32_t)kStreams;
     uint8_t* dst = c->d_outs[k];
+    // The stream: the next of the four while frames are in flight (they overlap); the SAME one for a frame that follows an
+    // awaited frame -- the reference's loop.  The work list of an awaited triangle frame is made from the previous frame of
+    // its stream: rotating regardless, that was the frame four steps back, and with the instances turning (the reference's
+    // scene spins one of its meshes) a list that old fitted the picture badly: 0.56 ms per frame against 0.38 with nothing
+    // moving (profiles/r04/loop_breakdown.log).
+    // (Frames of more than 32,768 tiles keep rotating: order_tiles is one workgroup -- 23 us for the reference's 17,808 tiles,
+    // 174 us for the 129,600 of a 4K frame -- and behind it on the same stream the next frame would wait for it.)
+    const bool big = (size_t)((c->W + 7u) / 8u) * local_tiles(c) > 32768u;
+    if (c->in_flight != 0u || big) c->stream_rot = (c->stream_rot + 1u) % (uint32_t)kStreams;
+    hipStream_t st = c->streams[c->stream_rot];
     // a streaming read-back (rt_read_pixels_async) may still be copying the frame this buffer holds
-    if (c->copy_pending[k]) RT_HIP(hipStreamWaitEvent(c->streams[k], c->ev_copy[k], 0));
-    int rc = rt_enqueue(c, dst, c->streams[k]);
+    if (c->copy_pending[k]) RT_HIP(hipStreamWaitEvent(st, c->ev_copy[k], 0));
+    int rc = rt_enqueue(c, dst, st);
     if (rc == RT_OK) { c->d_out = dst; c->buf_slot[k] = (int)c->in_flight - 1; ++c->frames_rendered; }
     return rc;
 }

@@ -55,7 +55,8 @@ struct rt_ctx {
     hipStream_t scene_stream = nullptr;  // ... recorded on this stream
     uint32_t in_flight = 0;              // frames enqueued since the last rt_wait
     hipStream_t slot_stream[RT355_MAX_IN_FLIGHT] = {nullptr};   // the stream each of them was enqueued on
-    uint32_t frames_rendered = 0;        // rt_render calls: parity selects stream and colour buffer
+    uint32_t frames_rendered = 0;        // rt_render calls: selects the colour buffer
+    uint32_t stream_rot = 0;             // the stream rt_render enqueues on: advances only while frames are in flight
     bool pipelined_hint = false;         // the last rt_wait completed frames on MORE THAN ONE of the library's own streams
                                          // (rt_render / rt_render_gather back to back): the caller keeps frames in flight
     uint32_t W = 0, H = 0;
