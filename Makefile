@@ -7,7 +7,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-fast-math -Wall -Wn
 SRCS     := $(sort $(wildcard $(CSRC)/*.hip $(CSRC)/*.h)) include/rt355.h
 # identity of the build: profiles (profiles/traffic.json) are evidence for the sources they were taken with
 BUILD_ID := $(shell cat $(SRCS) | sha256sum | cut -c1-16)
-OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_bvh.o $(CSRC)/rt_triangles.o $(CSRC)/rt_flow.o $(CSRC)/rt_assemble.o $(CSRC)/rt_comm.o
+OBJS     := $(CSRC)/rt_api.o $(CSRC)/rt_kernels.o $(CSRC)/rt_bvh.o $(CSRC)/rt_triangles.o $(CSRC)/rt_assemble.o $(CSRC)/rt_comm.o
 
 all: lib oracle node
 
@@ -24,10 +24,6 @@ $(CSRC)/rt_bvh.o: $(CSRC)/rt_bvh.hip $(CSRC)/rt_filter.h $(CSRC)/rt_device.h $(C
 $(CSRC)/rt_triangles.o: $(CSRC)/rt_triangles.hip $(CSRC)/rt_tri_device.h $(CSRC)/rt_device.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h include/rt355.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -fno-slp-vectorize -c $< -o $@
 
-# the persistent triangle kernel
-$(CSRC)/rt_flow.o: $(CSRC)/rt_flow.hip $(CSRC)/rt_flow_types.h $(CSRC)/rt_tri_device.h $(CSRC)/rt_device.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h include/rt355.h
-	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(CSRC)/rt_flow.resources.txt || (cat $(CSRC)/rt_flow.resources.txt; false)
-
 $(CSRC)/rt_assemble.o: $(CSRC)/rt_assemble.hip $(CSRC)/rt_types.h include/rt355.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -35,7 +31,7 @@ $(CSRC)/rt_api.o: $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -DRT355_BUILD_ID='"$(BUILD_ID)"' -c $(CSRC)/rt_api.hip -o $@
 
 # the RCCL entry points (rt_comm_init / rt_render_gather / rt_group_*)
-$(CSRC)/rt_comm.o: $(CSRC)/rt_comm.hip $(CSRC)/rt_ctx.h $(CSRC)/rt_flow_types.h $(CSRC)/rt_flow_build.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h $(CSRC)/rt_wait_poll.h $(CSRC)/rt_exchange_plan.h include/rt355.h
+$(CSRC)/rt_comm.o: $(CSRC)/rt_comm.hip $(CSRC)/rt_ctx.h $(CSRC)/rt_flow_build.h $(CSRC)/rt_types.h $(CSRC)/rt_tri_types.h $(CSRC)/rt_wait_poll.h $(CSRC)/rt_exchange_plan.h include/rt355.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

@@ -38,7 +38,7 @@ SYMBOLS = [
 
 # rt_kernel_id (include/rt355.h): which kernel form rendered a frame
 KERNEL_IDS = {0: "none", 1: "literal", 2: "brute_single", 3: "brute_pipeline", 4: "hierarchy_8", 5: "hierarchy_12",
-              6: "hierarchy_16", 7: "hierarchy_global", 8: "triangles", 9: "heatmap", 10: "triangles_flow", 11: "triangles_tiles"}
+              6: "hierarchy_16", 7: "hierarchy_global", 8: "triangles", 9: "heatmap"}
 
 
 class RtStats(ctypes.Structure):
@@ -49,6 +49,7 @@ class RtStats(ctypes.Structure):
         ("batch_frames", ctypes.c_uint32), ("batch_kernel_ms", ctypes.c_float),
         ("gather_ms", ctypes.c_float), ("batch_gather_ms", ctypes.c_float),
         ("kernel_id", ctypes.c_uint32), ("grid_share", ctypes.c_uint32), ("instance_uploads", ctypes.c_uint32),
+        ("pair_rebuilds", ctypes.c_uint32),
     ]
 
 

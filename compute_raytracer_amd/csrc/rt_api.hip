@@ -163,8 +163,6 @@ const char* rt_kernel_name(int id) {
         case RT_KID_HIERARCHY_GLOBAL: return "bvh_pixels<global>";
         case RT_KID_TRIANGLES: return "trace_triangles";
         case RT_KID_HEATMAP: return "heatmap_triangles";
-        case RT_KID_TRIANGLES_FLOW: return "trace_flow";
-        case RT_KID_TRIANGLES_TILES: return "trace_tiles";
         default: return "none";
     }
 }
@@ -242,7 +240,6 @@ int rt_destroy(rt_ctx* c) {
     (void)hipFree(c->d_bvh_rec);
     (void)hipFree(c->d_bvh_link);
     for (rt_ctx::DevBuf* b : {&c->d_tri, &c->d_tri_lookup, &c->d_tex, &c->d_corners, &c->d_flow}) (void)hipFree(b->p);
-    for (int k = 0; k < kStreams; ++k) (void)hipFree(c->d_flow_ovf[k].p);
     for (int k = 0; k < kStreams; ++k) { (void)hipFree(c->d_tile_cost[k].p); (void)hipFree(c->d_tile_order[k].p); }
     for (int v = 0; v < kVersions; ++v)
         for (rt_ctx::DevBuf* b : {&c->d_nodes[v], &c->d_blas[v], &c->d_blas_lookup[v]}) (void)hipFree(b->p);
@@ -591,7 +588,7 @@ int rt_set_mode(rt_ctx* c, int mode) {
 
 int rt_set_variant(rt_ctx* c, int variant) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_set_variant: ctx is NULL");
-    if (variant < 0 || variant > 8) return fail(RT_ERR_INVALID_ARG, "rt_set_variant: unknown variant");
+    if (variant < 0 || variant > 6) return fail(RT_ERR_INVALID_ARG, "rt_set_variant: unknown variant");
     c->variant = variant;
     return RT_OK;
 }
@@ -650,7 +647,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     bool sky_flat = true;       // six 1x1 faces of one colour
     for (int i = 0; i < 6; ++i)
         if (c->fw[i] != 1u || c->fh[i] != 1u || c->face_texel0[i] != c->face_texel0[0]) sky_flat = false;
-    bool resolve_pass = use_bvh && !sky_flat;      // rt_bvh.hip: sky_resolve (hierarchy kernel; the persistent triangle kernel joins below)
+    const bool resolve_pass = use_bvh && !sky_flat;      // rt_bvh.hip: sky_resolve
     if (resolve_pass) { int rc = ensure_fin(c); if (rc != RT_OK) return rc; }
     // The hierarchy after rt_write_spheres.  A changed sphere count (or the first frame): host build, here and
     // now.  The same count: the topology on the device stays, its node bounds are refitted there (below);
@@ -698,28 +695,30 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         c->scene_stream = s;
         c->corners_valid = true;
     }
-    // The persistent kernel (rt_flow.hip) takes scenes whose instance data travels with the frame (up to 16 instances) and
-    // whose indices fit 16 bits; it reads the BLAS trees from the relinked copy, rebuilt when a write has reached the nodes
-    // it was made from or a frame names a root it does not know.
-    bool use_flow = false;
-    RtFlowArgs fl;
-    std::memset(&fl, 0, sizeof fl);
-    bool have_pairs = false;       // the relinked copy is current and covers this frame's roots (also read by the default kernel)
-    const bool persistent = c->variant == 7 || c->variant == 8;
+    // The relinked pair records of the BLAS trees (rt_flow_build.h), for scenes whose instance data travels with the frame (up
+    // to 16 instances) and whose indices fit 16 bits: rebuilt when a write has reached the nodes the copy was made from or a
+    // frame names a root it does not know -- from the union of the roots it knows and the new ones, so that a host that
+    // alternates root sets between frames pays for each root once.
+    uint32_t root_meta[kInstMax] = {0};
+    bool have_pairs = false;       // the relinked copy is current and covers this frame's roots
     if (tri && c->kernel != RT_KERNEL_HEATMAP && c->variant != 6) {
         const uint32_t n_nodes = (uint32_t)(c->nodes_used / 32u);
         const uint32_t n_inst = (uint32_t)(c->inst.blas.size() / 20u);
-        const bool fits = c->inst.blas_on && c->inst.lookup_on && n_inst >= 1u && n_inst <= kFlowInst && !c->inst.lookup.empty() &&
-                          c->inst.lookup.size() <= kFlowInst && n_nodes >= 1u && n_nodes <= 65536u && c->d_tri_lookup.used / 4u <= 65536u &&
+        const bool fits = c->inst.blas_on && c->inst.lookup_on && n_inst >= 1u && n_inst <= kInstMax && !c->inst.lookup.empty() &&
+                          c->inst.lookup.size() <= kInstMax && n_nodes >= 1u && n_nodes <= 65536u && c->d_tri_lookup.used / 4u <= 65536u &&
                           c->node_count_max <= 65535u && c->h_nodes.size() / 8u >= n_nodes;
         if (fits) {
-            uint32_t roots[kFlowInst];
+            uint32_t roots[kInstMax];
             for (uint32_t i = 0; i < n_inst; ++i) roots[i] = rt_flow_u32f(c->inst.blas[20u * i + 16u]);
             // (the per-frame head of the node buffer lives in inst.head until a frame carries it: the mirror has it already)
-            if (c->flow_dirty || c->flow.n_nodes != n_nodes || !rt_flow_covers(c->flow, roots, n_inst)) {
+            const bool stale = c->flow_dirty || c->flow.n_nodes != n_nodes;
+            if (stale || !rt_flow_covers(c->flow, roots, n_inst)) {
                 { int rc = drain(c); if (rc != RT_OK) return rc; }
-                rt_flow_build(c->h_nodes.data(), n_nodes, roots, n_inst, c->flow);
+                std::vector<uint32_t> all(roots, roots + n_inst);
+                if (!stale) all.insert(all.end(), c->flow.roots.begin(), c->flow.roots.end());   // roots already known stay known
+                rt_flow_build(c->h_nodes.data(), n_nodes, all.data(), (uint32_t)all.size(), c->flow);
                 c->flow_dirty = false;
+                ++c->stats.pair_rebuilds;
                 if (c->flow.ok && c->flow.n_pairs) {
                     int rc = write_buf(c, c->d_flow, 0, c->flow.pairs.data(), (size_t)c->flow.n_pairs * 64u, "flow pairs");
                     if (rc != RT_OK) return rc;
@@ -727,27 +726,9 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             }
             have_pairs = c->flow.ok && c->flow.n_pairs != 0u;
             if (have_pairs) {
-                fl.n_pairs = c->flow.n_pairs;
                 const uint32_t last = n_nodes - 1u;
                 for (uint32_t i = 0; i < n_inst; ++i)
-                    fl.root_meta[i] = rt_flow_meta(c->h_nodes.data(), n_nodes, roots[i] < last ? roots[i] : last, c->flow.pair_of);
-            }
-            if (c->flow.ok && persistent) {
-                for (int k = 0; k < kStreams; ++k)
-                    if (!c->d_flow_ovf[k].p) {
-                        const size_t bytes = (size_t)c->n_cus * 16u * kFlowOvfWords * 4u;
-                        RT_HIP(hipMalloc(&c->d_flow_ovf[k].p, bytes));
-                        c->d_flow_ovf[k].cap = bytes;
-                    }
-                if (!sky_flat) { int rc = ensure_fin(c); if (rc != RT_OK) return rc; resolve_pass = true; }   // rt_flow.hip leaves records for sky_resolve too
-                use_flow = true;
-                fl.pairs = static_cast<const float4*>(c->d_flow.p);
-                fl.n_pairs = c->flow.n_pairs;
-                fl.thresh = 24u;
-                fl.static_pct = 75u;
-                const uint32_t last = n_nodes - 1u;
-                for (uint32_t i = 0; i < n_inst; ++i)
-                    fl.root_meta[i] = rt_flow_meta(c->h_nodes.data(), n_nodes, roots[i] < last ? roots[i] : last, c->flow.pair_of);
+                    root_meta[i] = rt_flow_meta(c->h_nodes.data(), n_nodes, roots[i] < last ? roots[i] : last, c->flow.pair_of);
             }
         }
     }
@@ -888,8 +869,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     const uint32_t order_n = ((c->W + 7u) / 8u) * fa.n_local_tiles;
     // ... and only for a caller that waits after each frame (the reference's loop): with frames in flight the tiles of
     // the next frame fill the slots a long tile leaves idle anyway, and row-major order keeps neighbours in one L2
-    const bool flow_steps = use_flow && c->variant == 7;     // the step machine takes pixels, not tiles: no order to choose
-    if (tri && !flow_steps && c->kernel != RT_KERNEL_HEATMAP && order_n >= kOrderMinTiles && !hint) {
+    if (tri && c->kernel != RT_KERNEL_HEATMAP && order_n >= kOrderMinTiles && !hint) {
         for (int k = 0; k < kStreams; ++k) if (s == c->streams[k]) order_set = k;
         if (order_set >= 0 && c->d_tile_cost[order_set].cap < (size_t)order_n * 4u) {
             // only frames on this stream use the set: wait for them, not for the batch (no slot bookkeeping involved)
@@ -926,9 +906,9 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         // two-byte stack entries (count << 14 | x): every meta of the records and of this frame's roots must fit them
         ts.p16_ok = (have_pairs && c->flow.max_count <= 3u && c->flow.max_x <= 16383u) ? 1u : 0u;
         for (uint32_t i = 0; i < 12u && ts.p16_ok; ++i)
-            if ((fl.root_meta[i] >> 16) > 3u || (fl.root_meta[i] & 0xFFFFu) > 16383u) ts.p16_ok = 0u;
+            if ((root_meta[i] >> 16) > 3u || (root_meta[i] & 0xFFFFu) > 16383u) ts.p16_ok = 0u;
         ts.pairs = (have_pairs && ts.n_blas <= 12u) ? static_cast<const float4*>(c->d_flow.p) : nullptr;
-        for (uint32_t i = 0; i < 12u; ++i) ts.root_meta[i] = fl.root_meta[i];
+        for (uint32_t i = 0; i < 12u; ++i) ts.root_meta[i] = root_meta[i];
 #ifdef RT355_DEV_EXPORTS
         if (order_set >= 0 && getenv("RT355_KEEP_TILE_COST")) RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));
 #endif
@@ -939,30 +919,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             if (getenv("RT355_TRI_NOLIST")) ts.tile_order = nullptr;
 #endif
         }
-        if (use_flow) {
-            // One 16-wave workgroup per CU when the frame has the chip to itself -- all the LDS the stacks leave goes to pair
-            // records --, one 4-wave workgroup per CU and frame when frames in flight share it.
-            uint32_t waves = fa.grid_share > 1u ? 4u : 16u, per_cu = fa.grid_share > 1u ? 4u : 1u, blocks = c->n_cus;
-#ifdef RT355_DEV_EXPORTS
-            if (const char* e = getenv("RT355_FLOW_WAVES")) { waves = (uint32_t)atoi(e); per_cu = 16u / waves; }
-            if (const char* e = getenv("RT355_FLOW_PERCU")) per_cu = (uint32_t)atoi(e);
-            if (const char* e = getenv("RT355_FLOW_BLOCKS")) blocks = (uint32_t)atoi(e);
-            if (const char* e = getenv("RT355_FLOW_THRESH")) fl.thresh = (uint32_t)atoi(e);
-            if (const char* e = getenv("RT355_FLOW_LDSPAIRS")) fl.lds_pairs_cap = (uint32_t)atoi(e) + 1u;
-            if (const char* e = getenv("RT355_FLOW_STATIC")) fl.static_pct = std::min(100u, (uint32_t)atoi(e));
-            if (waves != 16u && waves != 8u && waves != 4u) waves = 16u;
-            if (per_cu < 1u) per_cu = 1u;
-            if (blocks * waves > c->n_cus * 16u) blocks = c->n_cus * 16u / waves;      // the overflow area is sized for that many waves
-#endif
-            const uint32_t pixels = fa.n_local_tiles * ((fa.W + 7u) / 8u) * 64u;
-            blocks = std::max(1u, std::min(blocks, (pixels + 64u * waves - 1u) / (64u * waves)));
-            // one overflow area per frame that may be running: the frame kStreams slots back must be through with this one
-            if (slot >= (uint32_t)kStreams) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[slot - (uint32_t)kStreams], 0));
-            fl.ovf = static_cast<uint32_t*>(c->d_flow_ovf[slot % (uint32_t)kStreams].p);
-            RT_HIP(rt_launch_flow(fa, ts, fl, waves, per_cu, blocks, flow_steps, s));
-        } else {
-            RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
-        }
+        RT_HIP(rt_launch_triangles(fa, ts, c->kernel == RT_KERNEL_HEATMAP, s));
     } else {
         if (use_bvh) RT_HIP(rt_launch_bvh(fa, s));
         else RT_HIP(rt_launch_trace(fa, cfg, s));

@@ -4,7 +4,6 @@
 #include "../../include/rt355.h"
 #include "rt_types.h"
 #include "rt_tri_types.h"
-#include "rt_flow_types.h"
 #include "rt_flow_build.h"
 
 #include <cstdio>
@@ -128,13 +127,13 @@ struct rt_ctx {
     hipStream_t ver_stream[kVersions] = {nullptr};   // ... on this stream
     size_t nodes_used = 0;                       // bytes of the node buffer written so far (any version)
     uint32_t node_count_max = 0;                 // largest u32(primitiveCount) of any node written so far (packed BLAS stack: <= 65535)
-    // The persistent triangle kernel (rt_flow.hip) reads the BLAS trees from the library's relinked copy (rt_flow_build.h):
-    // built on the host from a mirror of the node buffer, when a frame first needs it or a write has touched what it was built from.
+    // The triangle kernel reads the BLAS trees from the library's relinked copy (rt_flow_build.h: pair records) where the scene
+    // fits it: built on the host from a mirror of the node buffer, when a frame first needs it or a write has touched what it
+    // was built from.
     std::vector<float> h_nodes;                  // mirror of the node buffer (every rt_write_nodes lands here too)
     RtFlow flow;
     bool flow_dirty = true;
     DevBuf d_flow;                               // the pair records
-    DevBuf d_flow_ovf[kStreams];                 // overflow stacks, one area per frame that may be running
     uint32_t n_cus = 256;
     uint32_t tex_w = 0, tex_h = 0;
     int scene_kind = 0;                    // 0 spheres, 1 triangles: the primitive type written last

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RT355_ABI_VERSION 3
+#define RT355_ABI_VERSION 4
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -64,9 +64,9 @@ typedef enum rt_kernel_id {
     RT_KID_HIERARCHY_16 = 6,     /* 16-wave workgroups, one per CU */
     RT_KID_HIERARCHY_GLOBAL = 7, /* nodes read from global memory (scenes beyond a CU's LDS) */
     RT_KID_TRIANGLES = 8,        /* trace_triangles (TLAS / BLAS traversal) */
-    RT_KID_HEATMAP = 9,          /* heatmap_triangles */
-    RT_KID_TRIANGLES_FLOW = 10,  /* trace_flow: persistent waves, one traversal step per trip, BLAS heads in LDS (rt_flow.hip) */
-    RT_KID_TRIANGLES_TILES = 11  /* trace_tiles: persistent waves, a tile per wave at a time, BLAS heads in LDS (rt_flow.hip) */
+    RT_KID_HEATMAP = 9           /* heatmap_triangles */
+    /* (10, 11: the persistent triangle kernels of ABI 3 -- measured slower on every configuration, removed in ABI 4;
+       docs/experiments.md keeps the account) */
 } rt_kernel_id;
 
 typedef enum rt_kernel {
@@ -104,6 +104,8 @@ typedef struct rt_stats {
                                      (frames on k distinct streams in flight)                 */
     uint32_t instance_uploads;    /* frames whose per-frame instance data (rt_write_blas / _blas_lookup /
                                      _nodes at offset 0) travelled with the frame, without a drain */
+    uint32_t pair_rebuilds;       /* times the library rebuilt its relinked copy of the BLAS trees (a drain + an upload:
+                                     a node write reached the trees, or a frame named a root the copy did not know) */
 } rt_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------- */
@@ -183,9 +185,8 @@ int rt_set_mode(rt_ctx* ctx, int mode);
  * 4 = hierarchy for any sphere count; 5 = brute force (two-kernel pipeline from 320 spheres on);
  * 1, 2, 3 = individual brute-force forms.  Triangle scenes: 0 = one workgroup per tile (rt_triangles.hip), reading the BLAS
  * trees from the library's relinked pair records where the scene fits them (up to 12 instances, node buffer and lookup table
- * within 16-bit indices); 6 = the same kernel on the reference's node buffer only; 7 / 8 = the persistent kernels of rt_flow.hip
- * -- the step machine trace_flow / the tile loop trace_tiles -- for scenes of up to 16 instances (others fall back to 0):
- * measured slower than the default, kept selectable.  Every variant produces the same pixels.  See DESIGN.md. */
+ * within 16-bit indices); 6 = the same kernel on the reference's node buffer only.  Every variant produces the same pixels.
+ * See DESIGN.md. */
 int rt_set_variant(rt_ctx* ctx, int variant);
 
 /* ---- multi-GPU partition --------------------------------------------------------------- */

@@ -51,7 +51,7 @@ from compute_raytracer_amd.procedural import obj_floor, obj_uv_sphere, tri_buffe
 
 
 def gpu_render_tri(scene, material, width, height, bounces, skybox=None, heatmap=False, variant=0):
-    """variant 0: the library's choice (one workgroup per tile), 7: the step machine, 8: the persistent tile loop (rt_flow.hip)."""
+    """variant 0: the library's choice (pair records where the scene fits them), 6: the reference's node buffer only."""
     import compute_raytracer_amd as rt
     r = rt.RendererRaytracing(width, height, scene, maxBounces=bounces)
     r.initialize(skybox, material)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "librt355.so does not export %s" % n
     assert sorted(abi.SYMBOLS) == names, "abi.SYMBOLS is out of sync with include/rt355.h"
-    assert lib.rt_abi_version() == 3
+    assert lib.rt_abi_version() == 4
     assert len(lib.rt_build_id()) == 16 and lib.rt_kernel_name(4) == b"bvh_pixels<8>"
 
 

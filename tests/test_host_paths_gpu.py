@@ -92,8 +92,7 @@ def test_stats_name_the_kernel_form():
     r = rt.RendererRaytracing(128, 80, scene, maxBounces=2).initialize(rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA), mat)
     try:
         r.render(); assert abi.KERNEL_IDS[r.stats()["kernel_id"]] == "triangles"
-        r.set_variant(8); r.render(); assert abi.KERNEL_IDS[r.stats()["kernel_id"]] == "triangles_tiles"
-        r.set_variant(7); r.render(); assert abi.KERNEL_IDS[r.stats()["kernel_id"]] == "triangles_flow"; r.set_variant(0)
+        r.set_variant(6); r.render(); assert abi.KERNEL_IDS[r.stats()["kernel_id"]] == "triangles"; r.set_variant(0)
         r.showHeatmap(); r.render(); assert abi.KERNEL_IDS[r.stats()["kernel_id"]] == "heatmap"
     finally:
         r.close()

@@ -1,7 +1,6 @@
 #!/bin/bash
 # Development builds of the library (build container): tools/bin/librt355_dev.so reads its launch knobs from the environment
-# (RT355_FLOW_WAVES / _PERCU / _BLOCKS / _THRESH, RT355_BVH_TAIL / _BLOCKS ...), tools/bin/librt355_fc.so is the counting build
-# of the persistent triangle kernel (rt_debug_flow_counts).  Neither ships; tests and bench.py load compute_raytracer_amd/librt355.so.
+# (RT355_TRI_*, RT355_BVH_TAIL / _BLOCKS ...).  It does not ship; tests and bench.py load compute_raytracer_amd/librt355.so.
 set -e
 cd "$(dirname "$0")/.."
 CS=compute_raytracer_amd/csrc
@@ -10,11 +9,8 @@ mkdir -p tools/bin /tmp/rtdev
 make -s lib
 /opt/rocm/bin/hipcc $FL -DRT355_DEV_EXPORTS -DRT355_BUILD_ID='"dev"' -c $CS/rt_api.hip -o /tmp/rtdev/rt_api.o &
 /opt/rocm/bin/hipcc $FL -fno-slp-vectorize -DRT_BVH_DEV_ENV -c $CS/rt_bvh.hip -o /tmp/rtdev/rt_bvh.o &
-/opt/rocm/bin/hipcc $FL -fno-slp-vectorize -DRT_FLOW_COUNT -c $CS/rt_flow.hip -o /tmp/rtdev/rt_flow_count.o &
 /opt/rocm/bin/hipcc $FL -fno-slp-vectorize -DRT_TRI_DEV_ENV -c $CS/rt_triangles.hip -o /tmp/rtdev/rt_triangles.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/bin/librt355_dev.so /tmp/rtdev/rt_api.o /tmp/rtdev/rt_bvh.o \
-    $CS/rt_kernels.o /tmp/rtdev/rt_triangles.o $CS/rt_flow.o $CS/rt_assemble.o $CS/rt_comm.o -L/opt/rocm/lib -lrccl
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/bin/librt355_fc.so /tmp/rtdev/rt_api.o /tmp/rtdev/rt_bvh.o \
-    $CS/rt_kernels.o $CS/rt_triangles.o /tmp/rtdev/rt_flow_count.o $CS/rt_assemble.o $CS/rt_comm.o -L/opt/rocm/lib -lrccl
+    $CS/rt_kernels.o /tmp/rtdev/rt_triangles.o $CS/rt_assemble.o $CS/rt_comm.o -L/opt/rocm/lib -lrccl
 ls -la tools/bin/*.so

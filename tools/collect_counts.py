@@ -18,7 +18,7 @@ def build():
     csrc = os.path.join(ROOT, "compute_raytracer_amd", "csrc")
     os.makedirs(os.path.join(ROOT, "tools", "bin"), exist_ok=True)
     flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -Wall -Wno-unused-function -ffp-contract=off -fno-slp-vectorize".split()
-    objs = [os.path.join(csrc, o) for o in ("rt_api.o", "rt_kernels.o", "rt_triangles.o", "rt_flow.o", "rt_assemble.o", "rt_comm.o")]
+    objs = [os.path.join(csrc, o) for o in ("rt_api.o", "rt_kernels.o", "rt_triangles.o", "rt_assemble.o", "rt_comm.o")]
     for m in MODES:
         obj = "/tmp/rt_bvh_c%d.o" % m
         subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-DRT_BVH_COUNT=%d" % m, "-c", os.path.join(csrc, "rt_bvh.hip"), "-o", obj], check=True)

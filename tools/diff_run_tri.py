@@ -1,8 +1,7 @@
 """One-off differential run (development): random procedural triangle scenes through trace_triangles and the
 heatmap kernel against the CPU oracle -- instance counts, tessellations, cameras, skies, bounce limits, frame sizes.
-Round 4: every scene through all four ray-trace variants (0: one workgroup per tile over the relinked pair records, 6: over
-the node buffer, 7: the step machine, 8: the persistent tile loop), frames one at a time and -- every fifth scene -- four
-frames in flight with the instances moving.
+Every scene through both ray-trace variants (0: one workgroup per tile over the relinked pair records, 6: over the node
+buffer), frames one at a time and -- every fifth scene -- four frames in flight with the instances moving.
 usage: python tools/diff_run_tri.py [scenes=120] [first seed=7000]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,14 +30,14 @@ for seed in range(first, first + count):
     bufs = tri_buffers(scene, mat)
     ref, _, rays = oracle.render_tri(scene.pack_params(B), bufs, sky.faces, W, H)
     ok = True
-    for variant in (0, 6, 7, 8):
+    for variant in (0, 6):
         img, st = gpu_render_tri(scene, mat, W, H, B, skybox=sky, variant=variant)
         ok = ok and np.array_equal(img, ref) and st["rays"] == rays
     href, _ = oracle.heatmap_tri(scene.pack_params(B), bufs, W, H)
     himg, _ = gpu_render_tri(scene, mat, W, H, B, skybox=sky, heatmap=True)
     ok = ok and np.array_equal(himg, href)
     if (seed - first) % 5 == 4:                       # frames in flight, instances moving, each against the oracle
-        for variant in (0, 7, 8):
+        for variant in (0, 6):
             r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
             r.set_variant(variant)
             host, want = r.host_frames(4), []

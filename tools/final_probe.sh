@@ -6,4 +6,4 @@ for cfg in C3 C5; do
     KNOB_WORLD=$w timeout -k 10 120 python tools/knob_ab.py "$cfg world=$w" 2>&1 | grep "in flight"
   done
 done
-timeout -k 10 200 python tools/flow_probe.py v0 2>&1 | grep -v amdgpu
+timeout -k 10 200 python tools/tri_ab_probe.py v0 2>&1 | grep -v amdgpu

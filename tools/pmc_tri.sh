@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes of a triangle configuration one frame at a time: tools/pmc_flow.sh <out dir> <REF|TRI|TRI4K> <variant> ; then tools/pmc_flow_summary.py <out dir>
+# PMC passes of a triangle configuration one frame at a time: tools/pmc_tri.sh <out dir> <REF|TRI|TRI4K> <variant> ; then tools/pmc_tri_summary.py <out dir>
 set -e
 OUT=$1; CFG=${2:-REF}; V=${3:-0}
 mkdir -p $OUT
@@ -11,7 +11,7 @@ P4="SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
-  rocprofv3 --output-format csv --pmc $P -d $OUT/p$i -o p -- python3 tools/flow_frames.py $CFG 6 $V > $OUT/p$i.out 2> $OUT/p$i.err || { tail -5 $OUT/p$i.err; }
+  rocprofv3 --output-format csv --pmc $P -d $OUT/p$i -o p -- python3 tools/tri_frames.py $CFG 6 $V > $OUT/p$i.out 2> $OUT/p$i.err || { tail -5 $OUT/p$i.err; }
   f=$(find $OUT/p$i -name "*counter_collection.csv" | head -n 1)
   [ -n "$f" ] && cp "$f" $OUT/${CFG}-v${V}__p$i.csv
   rm -rf $OUT/p$i

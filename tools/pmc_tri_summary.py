@@ -1,4 +1,4 @@
-"""Per-kernel averages of the PMC passes tools/pmc_flow.sh took: python3 tools/pmc_flow_summary.py <dir>"""
+"""Per-kernel averages of the PMC passes tools/pmc_tri.sh took: python3 tools/pmc_tri_summary.py <dir>"""
 import csv, glob, os, sys, collections
 d = sys.argv[1]
 for f in sorted(glob.glob(os.path.join(d, "*__p*.csv"))):

@@ -2,7 +2,7 @@
 scene (REF), the procedural scene of its size at 1344x846 (TRI) and at 3840x2160 (TRI4K).  Per configuration and
 variant: the frame's sha256 (both kernels must agree), kernel time one frame at a time (hipEvents, min / median) and
 wall time per frame with frames in flight.
-usage: [RT355_LIB=tools/bin/librt355_dev.so RT355_FLOW_WAVES=.. RT355_FLOW_THRESH=..] python tools/flow_probe.py [REF TRI TRI4K] [v0 v6] [label]"""
+usage: [RT355_LIB=tools/bin/librt355_dev.so RT355_TRI_...=..] python tools/tri_ab_probe.py [REF TRI TRI4K] [v0 v6] [label]"""
 import hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,9 +13,9 @@ from compute_raytracer_amd.scene_raytracing import CONSTANT_SKY_RGBA
 
 args = sys.argv[1:]
 configs = [a for a in args if a in ("REF", "TRI", "TRI4K")] or ["REF", "TRI", "TRI4K"]
-variants = [int(a[1:]) for a in args if a in ("v0", "v6", "v7", "v8")] or [0, 6]
-label = " ".join("%s=%s" % (k[6:], v) for k, v in sorted(os.environ.items()) if k.startswith("RT355_FLOW")) + " " + \
-        " ".join(a for a in args if a not in ("REF", "TRI", "TRI4K", "v0", "v6", "v7"))
+variants = [int(a[1:]) for a in args if a in ("v0", "v6")] or [0, 6]
+label = " ".join("%s=%s" % (k[6:], v) for k, v in sorted(os.environ.items()) if k.startswith("RT355_TRI")) + " " + \
+        " ".join(a for a in args if a not in ("REF", "TRI", "TRI4K", "v0", "v6"))
 _tri = None
 for name in configs:
     if name == "REF":

@@ -1,4 +1,4 @@
-"""N frames one at a time of a triangle configuration (for rocprofv3 passes): python3 tools/flow_frames.py REF|TRI|TRI4K [frames] [variant]"""
+"""N frames one at a time of a triangle configuration (for rocprofv3 passes): python3 tools/tri_frames.py REF|TRI|TRI4K [frames] [variant]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
