@@ -3,6 +3,9 @@
 BASELINE.json's configuration C3 (3840x2160, 1024 spheres, 8 bounces), on N GPUs of one node.
 
     python bench.py                                  (= --gpus 1 --steps 100 --warmup 5)
+    python bench.py --gpus N --steps K --warmup W    (N > 1 without a launcher: starts the line below as a CHILD process --
+                                                      before anything here has touched torch or HIP --, relays rank 0's JSON
+                                                      line and the exit code; --dry-launch prints the child's command instead)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -81,6 +84,8 @@ def parse():
                     help="N > 1: tiles go to rank 0 only (grouped ncclSend/ncclRecv) or to every rank (ncclAllGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="--gpus N > 1 without a launcher: print the torch.distributed.run command the ranks would be started with, and exit")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N>1 code path (rt_comm_init + rt_render_gather) even with one rank; used by "
                          "tests/test_bench_gpu.py to exercise that path on a 1-GPU box")
@@ -168,8 +173,33 @@ def golden_frame(name):
         return None
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): the ranks are started
+    as a child `python -m torch.distributed.run` of THIS process, which has not imported torch nor made any HIP call and makes
+    none afterwards -- it relays the child's stdout (rank 0's one JSON line) and stderr, and exits with the child's code.
+    (Never an exec: replacing a process is fine only before the GPU has been touched, and a child is fine always.)"""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:                  # a free port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    argv = [x for x in sys.argv[1:] if x != "--dry-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + argv
+    if a.dry_launch:
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")           # torchrun would set it, with a warning on stderr
+    return subprocess.run(cmd, env=env).returncode  # stdout / stderr are inherited: the JSON line arrives as the child prints it
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     # stdout carries ONE line, the JSON.  Libraries print banners there from native code (gloo: "[Gloo] Rank 0 is
     # connected ...", RCCL: its version block at the first communicator), so file descriptor 1 points at stderr
     # until the line is ready.
@@ -180,9 +210,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
-        a.gpus = world
+        a.gpus = world                    # a launcher's WORLD_SIZE is what there is
 
     import torch  # torch.distributed (control plane) and torch.cuda.synchronize only; no tensor touches the data path
     import compute_raytracer_amd as rt

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rt_bvh_build.h"
+#include "rt_tlas_fit.h"
 
 thread_local std::string g_rt_err;
 thread_local int g_rt_kernel_id = 0;
@@ -903,6 +904,13 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
         ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u;
+        // the top-level tree this frame walks (the mirror holds every node write, per-frame heads included): small enough for the
+        // four-slot TLAS stack?  (rt_tlas_fit.h; the same constants as the kernel's: rt_tri_device.h kSmallStack / kSmallNodes)
+        ts.tlas_small = 0u;
+        if (c->h_nodes.size() / 8u >= ts.n_nodes) {
+            if (ts.n_blas <= 4u && rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 3u, 8u)) ts.tlas_small = 2u;
+            else if (rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 4u, 16u)) ts.tlas_small = 1u;
+        }
         // two-byte stack entries (count << 14 | x): every meta of the records and of this frame's roots must fit them
         ts.p16_ok = (have_pairs && c->flow.max_count <= 3u && c->flow.max_x <= 16383u) ? 1u : 0u;
         for (uint32_t i = 0; i < 12u && ts.p16_ok; ++i)

@@ -274,6 +274,12 @@ __device__ __forceinline__ void report_fault(unsigned long long* counter, unsign
     if (threadIdx.x == 0) atomicMax(counter + 1, code);
 }
 
+// ... for a kernel that has added its wave's rays up already: called by ONE lane of the wave
+__device__ __forceinline__ void count_wave_rays(unsigned long long* counter, uint32_t wave_rays) {
+    const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    atomicAdd(counter + (size_t)(wave_id % RT_RAY_COUNTERS) * (RT_RAY_COUNTER_STRIDE / 8u), (unsigned long long)wave_rays);
+}
+
 __device__ __forceinline__ void count_rays(unsigned long long* counter, uint32_t nrays) {
     const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     unsigned long long* part = counter + (size_t)(wave_id % RT_RAY_COUNTERS) * (RT_RAY_COUNTER_STRIDE / 8u);

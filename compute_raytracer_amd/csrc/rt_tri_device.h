@@ -1,6 +1,5 @@
-// rt_tri_device.h -- device-side pieces of the triangle path shared by its kernels (rt_triangles.hip: pixel per lane,
-// one tile per wave; rt_flow.hip: persistent waves, one traversal step per trip): the reference's node, box, triangle and
-// texture arithmetic (RK:168-410), every expression in the oracle's order.  Include after rt_device.h / rt_tri_types.h in a
+// rt_tri_device.h -- device-side pieces of the triangle path (rt_triangles.hip: pixel per lane, one tile per wave): the
+// reference's node, box, triangle and texture arithmetic (RK:168-410), every expression in the oracle's order.  Include after rt_device.h / rt_tri_types.h in a
 // translation unit compiled with -ffp-contract=off.
 #pragma once
 #include <type_traits>
@@ -18,6 +17,12 @@ __device__ __forceinline__ uint32_t u32f(float f) {               // WGSL u32(f3
     return f >= 4294967040.0f ? 4294967295u : (uint32_t)f;
 }
 __device__ __forceinline__ uint32_t sclamp(uint32_t i) { return i > kStack - 1u ? kStack - 1u : i; }
+// The TLAS stack of a frame whose top-level tree the host has walked (rt_tlas_fit.h): no leaf deeper than kSmallStack levels,
+// every node among the first kSmallNodes -- the stack pointer then never passes kSmallStack, the guard of RK:212 (20) is out
+// of reach, and four slots hold what the reference keeps in twenty.  (Indexing clamps to the slots there are all the same.)
+constexpr uint32_t kSmallStack = 4u, kSmallNodes = 16u;
+constexpr uint32_t kTinyStack = 3u, kTinyNodes = 8u, kTinyBlas = 4u;    // ... and the form for up to four instances
+template <uint32_t TS> __device__ __forceinline__ uint32_t tclamp(uint32_t i) { return i > TS - 1u ? TS - 1u : i; }
 
 struct NodeR { v3 lo; float left; v3 hi; float count; };
 __device__ __forceinline__ NodeR load_node(const RtTriScene& T, uint32_t i) {
@@ -44,11 +49,11 @@ __device__ __forceinline__ NodeR load_node_head(const RtTriScene& T, const TriLd
     n.hi = V(b.x, b.y, b.z); n.count = b.w;
     return n;
 }
-template <int WAVES>
+template <int WAVES, uint32_t NODES = kLdsNodes, uint32_t BLAS = kLdsBlas>
 __device__ __forceinline__ TriLds stage_head(const RtTriScene& T, float4* s_nodes, float* s_blas) {
     TriLds L;
-    L.n_nodes = T.n_nodes < kLdsNodes ? T.n_nodes : kLdsNodes;
-    L.n_blas = T.n_blas < kLdsBlas ? T.n_blas : kLdsBlas;
+    L.n_nodes = T.n_nodes < NODES ? T.n_nodes : NODES;
+    L.n_blas = T.n_blas < BLAS ? T.n_blas : BLAS;
     for (uint32_t i = threadIdx.x; i < 2u * L.n_nodes; i += 64 * WAVES) s_nodes[i] = T.nodes[i];
     // (the last padding word of staged record k carries entry k of the BLAS lookup table, RK:223: one dependent global load
     // less per instance and ray)
@@ -261,7 +266,7 @@ __device__ __forceinline__ void trace_blas(const RtTriScene& T, const TriLds& L,
 }
 
 // RK:168-244 traceTLAS.  tstack / bstack: this lane's two LDS stacks.
-template <bool COUNT, typename STK, bool PACKED, bool PAIRS = false, bool P16 = false>
+template <bool COUNT, typename STK, bool PACKED, bool PAIRS = false, bool P16 = false, uint32_t TS = kStack>
 __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& L, v3 o, v3 d, STK* tstack,
                                              typename std::conditional<PACKED && !P16, uint32_t, STK>::type* bstack, uint32_t stride, float& traces) {
     TriHit hit; hit.t = 0.0f; hit.u = hit.v = 0.0f; hit.tri = -1; hit.blas = -1;   // RK:170-171
@@ -283,11 +288,11 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
             if (d1 > nearest) {                                     // RK:198
                 if (sp == 0u) break;
                 sp -= 1u;
-                node = load_node_head(T, L, tstack[sclamp(sp) * stride]);
+                node = load_node_head(T, L, tstack[tclamp<TS>(sp) * stride]);
             } else {
                 node = swap ? c2 : c1;                              // RK:208
                 if (d2 < nearest) {                                 // RK:209
-                    tstack[sclamp(sp) * stride] = (STK)(i2 < T.n_nodes ? i2 : T.n_nodes - 1u);
+                    tstack[tclamp<TS>(sp) * stride] = (STK)(i2 < T.n_nodes ? i2 : T.n_nodes - 1u);
                     sp += 1u;
                     // RK:212-214 guards with `>`, the heatmap twin with `>=` (HK:168)
                     if (COUNT ? sp >= kStack : sp > kStack) sp = kStack - 1u;
@@ -303,7 +308,7 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
             }
             if (sp == 0u) break;                                    // RK:233
             sp -= 1u;
-            node = load_node_head(T, L, tstack[sclamp(sp) * stride]);       // RK:237-238
+            node = load_node_head(T, L, tstack[tclamp<TS>(sp) * stride]);   // RK:237-238
         }
     }
     return hit;

@@ -12,6 +12,8 @@ struct RtTriScene {
     const uint8_t* tex;        // meshTex, rgba8unorm
     uint32_t n_nodes, n_blas, n_tri, n_tri_lookup, n_blas_lookup, tex_w, tex_h;
     uint32_t packed_ok;        // every node's count, child index and lookup slot fits 16 bits: the BLAS stack may hold (count, left)
+    uint32_t tlas_small;       // the host walked this frame's top-level tree (rt_tlas_fit.h): 1 = leaves at most 4 levels down, all nodes among
+                               // the first 16; 2 = at most 3 levels, 8 nodes, 4 instances; 0 = neither
     uint32_t p16_ok;           // ... and (count << 14 | x) fits 16: leaves of at most 3 triangles, at most 16,384 pair records and lookup slots
     // Work list (rt_triangles.hip: order_tiles): tile_order[0] tiles are rendered as four quarters, tile_order[1...] is the
     // order of the tiles (null: every tile whole, in index order); every workgroup adds the time it took to

@@ -31,18 +31,76 @@
 namespace rtk {
 
 // ---- kernel: RK main over the triangle scene ---------------------------------------------------------
-// FLAT: compiled for a one-colour 1x1 sky (A.sky_flat) -- no cube filtering code inside the traversal's register budget.
-template <int WAVES, typename STK, int OCC, bool FLAT, bool PACKED, bool PAIRS = false, bool P16 = false>
+// What a path carries across a traversal, and where.  The two traversals of a bounce (RK:114, RK:153) are the kernel: the
+// registers they need decide how many waves a SIMD holds.  Everything the bounce loop needs AFTER a traversal but not IN it
+// is therefore (a) reduced to what will be used -- the shading of a hit is formed before its shadow ray is cast: the light
+// term down to the one product that the shadow test switches on or off (RK:160-162), albedo and texture sample (RK:133-134)
+// as their sum; the running mean's weights `affect` and `sum` (RK:139-140) are the same for every lane still in the loop
+// and live in scalar registers -- and (b) in the SMALL form parked in LDS, one dword per lane and value, slot-major like the
+// stacks (a wave's access touches 64 banks).  Round 4's five-wave form left that choice to the register allocator: 10-13
+// dwords of scratch per lane, 56 MB of HBM writes per frame of the reference's scene for a 4.5 MB picture.
+//   slot 0-2 colour, 3 dist (written once, at bounce 0), 4 the lit intensity, 5-7 albedo, 8-10 the reflected direction;
+//   a lane that LEAVES the loop on a miss reuses 4-10 for what its sky sample needs: direction, affect, sum.
+// The sky a path escapes into (RK:122-126) is sampled after the loop, by all lanes of the wave that ended on a miss at once
+// (inside the loop the filter ran for the lanes that missed at THAT bounce while the others waited), through the same one
+// copy of the filter that then samples the fog colour (RK:92): a loop of one or two trips.
+template <int PARK, uint32_t STRIDE> struct Parked;
+template <uint32_t STRIDE> struct Parked<0, STRIDE> {              // no LDS to spare: the values stay where the compiler puts them
+    float r[11];
+    __device__ __forceinline__ explicit Parked(float*) {}
+    template <int K> __device__ __forceinline__ void put(float v) { r[K] = v; }
+    template <int K> __device__ __forceinline__ float get() const { return r[K]; }
+};
+template <int PARK, uint32_t STRIDE> struct Parked {
+    static_assert(PARK >= 11, "eleven values are parked");
+    typedef volatile __attribute__((address_space(3))) float* lds_f32;   // an LDS address (ds_write_b32 / ds_read_b32 with the slot as
+    lds_f32 base;                                                          // immediate offset); volatile: a store is a store, a load a load
+    __device__ __forceinline__ explicit Parked(float* lane_column) : base((lds_f32)lane_column) {}
+    template <int K> __device__ __forceinline__ void put(float v) { base[K * STRIDE] = v; }
+    template <int K> __device__ __forceinline__ float get() const { return base[K * STRIDE]; }
+};
+// one ray per lane that is here: counted per wave, by one lane, in LDS -- not in a register of every lane
+__device__ __forceinline__ void count_traversal(uint32_t lane, uint32_t* wave_rays) {
+    const uint64_t here = __ballot(1);
+    if (lane == (uint32_t)__builtin_amdgcn_readfirstlane((int)lane)) *wave_rays += (uint32_t)__popcll(here);
+}
+// The frame's arguments, read AGAIN from the kernarg segment (they are the kernel's first parameter: offset 0): what the
+// epilogue needs of them -- camera basis, sky faces, sizes, the output pointer -- then does not sit in scalar registers through
+// the traversals (the loop's own constants, exec masks of six nested divergent levels and the buffer pointers fill the 102 there are;
+// what did not fit went to lanes of a VGPR, and to a scratch frame the dispatcher had to provide although nothing was ever stored in it).
+__device__ __forceinline__ const RtFrameArgs& reread_first_kernarg() {
+    typedef const __attribute__((address_space(4))) RtFrameArgs* kernarg_ptr;
+    kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                                   // opaque: not the pointer the prologue loaded from
+    return *(const RtFrameArgs*)p;
+}
+__device__ __forceinline__ float uniform(float v) {               // a value every ACTIVE lane holds: keep it in a scalar register
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// FLAT: compiled for a one-colour 1x1 sky (A.sky_flat) -- no cube filtering code at all.
+// SMALL: the frame's top-level tree passed rt_tlas_fits (rt_tlas_fit.h).  1: kSmallStack TLAS slots, kSmallNodes staged nodes,
+// and the LDS that frees is the parking place above (7,360 bytes per wave: five waves per SIMD);  2: kTinyStack slots, kTinyNodes
+// nodes, kTinyBlas instance records (6,336 bytes per wave: six waves per SIMD fit a CU's 160 KB).
+template <int WAVES, typename STK, int OCC, bool FLAT, bool PACKED, bool PAIRS = false, bool P16 = false, int SMALL = 0>
 __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
     typedef typename std::conditional<PACKED && !P16, uint32_t, STK>::type BSTK;
-    __shared__ STK tstacks[kStack * 64 * WAVES];
+    constexpr uint32_t TS = SMALL == 2 ? kTinyStack : (SMALL == 1 ? kSmallStack : kStack);
+    constexpr uint32_t NODES = SMALL == 2 ? kTinyNodes : (SMALL == 1 ? kSmallNodes : kLdsNodes);
+    constexpr uint32_t BLAS = SMALL == 2 ? kTinyBlas : kLdsBlas;
+    constexpr int PARK = SMALL ? 11 : 0;
+    __shared__ STK tstacks[TS * 64 * WAVES];
     __shared__ BSTK bstacks[kStack * 64 * WAVES];
     STK* tstack = tstacks + threadIdx.x;
     BSTK* bstack = bstacks + threadIdx.x;
     constexpr uint32_t stride = 64 * WAVES;
-    __shared__ float4 s_nodes[2 * kLdsNodes];
-    __shared__ float s_blas[20 * kLdsBlas];
-    const TriLds L = stage_head<WAVES>(T, s_nodes, s_blas);
+    __shared__ float4 s_nodes[2 * NODES];
+    __shared__ float s_blas[20 * BLAS];
+    __shared__ float s_park[PARK ? PARK * 64 * WAVES : 1];
+    __shared__ uint32_t s_rays[WAVES];             // traversals of this wave's lanes (the frame's ray counter, RK:114 + RK:153)
+    if ((threadIdx.x & 63u) == 0u) s_rays[threadIdx.x >> 6] = 0u;
+    Parked<PARK, stride> pk(s_park + threadIdx.x);
+    const TriLds L = stage_head<WAVES, NODES, BLAS>(T, s_nodes, s_blas);
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // one workgroup per tile, or per quarter of a tile the previous frame on this stream found long (order_tiles)
@@ -79,48 +137,89 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     if (x >= A.W || y >= A.H) return;          // thread 0 leaves here only with its whole tile or part: its pixel is their first
 
     const Scene sc = unpack_scene(A);
-    uint32_t nrays = 0;
     float dummy = 0.0f;
-    float dist = 0.0f;
-    v3 color = V(1.0f, 1.0f, 1.0f);
+    pk.template put<0>(1.0f); pk.template put<1>(1.0f); pk.template put<2>(1.0f);   // color = (1, 1, 1), RK:103
+    pk.template put<3>(0.0f);                                                        // dist: 0 unless the primary ray hits (RK:116-118)
     v3 ro = sc.cameraPos, rd = primary_dir(A, sc, x, y);
     float affect = 1.0f, sum = 0.0f;
+    bool missed = false;
     for (uint32_t bounce = 0; bounce < sc.bounces; ++bounce) {                       // RK:113
-        const TriHit h = trace_tlas<false, STK, PACKED, PAIRS, P16>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
-        ++nrays;
-        const bool hit = h.tri >= 0;
-        if (bounce == 0) dist = hit ? h.t : 0.0f;                                    // RK:116-118
-        const float next = affect + sum;                                             // RK:120
-        if (!hit) {                                                                  // RK:122-126
-            const v3 sky = scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, rd));
-            color = divs(add(scale(sum, color), scale(affect, sky)), next);
+        affect = uniform(affect); sum = uniform(sum);                                // 2^-bounce, 2 - 2^(1-bounce): one value per wave
+        const TriHit h = trace_tlas<false, STK, PACKED, PAIRS, P16, TS>(T, L, ro, rd, tstack, bstack, stride, dummy); // RK:114
+        count_traversal(lane, &s_rays[wave]);
+        if (h.tri < 0) {                                                             // RK:122-126: sampled after the loop
+            pk.template put<4>(rd.x); pk.template put<5>(rd.y); pk.template put<6>(rd.z);
+            pk.template put<7>(affect); pk.template put<8>(sum);
+            missed = true;
             break;
         }
+        if (bounce == 0) pk.template put<3>(h.t);                                    // RK:116-118
+        const float next = affect + sum;                                             // RK:120
         const v3 normal = hit_normal(T, h);
-        const int tri = h.tri;
-        const float hu = h.u, hv = h.v;
+        const Albedo s = hit_albedo(T, h.tri, h.u, h.v);
         ro = add(ro, scale(h.t, rd));                                                // RK:129
         rd = normalize(reflect(rd, normal));                                         // RK:130
-        // RK:146-166
-        const v3 sdir = normalize(sub(ro, sc.lightPos));
-        const float distance = length(sdir);
-        const TriHit sh = trace_tlas<false, STK, PACKED, PAIRS, P16>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
-        ++nrays;
-        const float intensity = light_term(sc, ro, normal, sdir, distance, sh.tri >= 0, sh.t);
-        const Albedo s = hit_albedo(T, tri, hu, hv);
-        const v3 diffuseColor = scale(s.w, s.rgb);                                   // RK:133
-        const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));        // RK:134
-        const v3 blended = scale(intensity, add(diffuseColor, samplerColor));        // RK:135
-        color = divs(add(scale(sum, color), scale(affect, blended)), next);          // RK:136
+        // RK:146-166 lightIntensity: everything but the shadow ray's verdict is known before the ray is cast
+        const v3 sdir = normalize(sub(ro, sc.lightPos));                             // RK:147
+        const float distance = length(sdir);                                         // RK:148
+        {
+            const float power = clampf(dot(normal, V(-sdir.x, -sdir.y, -sdir.z)), sc.minIntensity, 1.0f);   // RK:160
+            const float cap = sc.lightIntensity / (sc.lightIntensity + distance);                           // RK:161
+            pk.template put<4>(power * cap);                                                                // RK:162
+            const v3 diffuseColor = scale(s.w, s.rgb);                               // RK:133
+            const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));    // RK:134
+            const v3 albedo = add(diffuseColor, samplerColor);                       // RK:135, the sum
+            pk.template put<5>(albedo.x); pk.template put<6>(albedo.y); pk.template put<7>(albedo.z);
+            pk.template put<8>(rd.x); pk.template put<9>(rd.y); pk.template put<10>(rd.z);
+        }
+        const TriHit sh = trace_tlas<false, STK, PACKED, PAIRS, P16, TS>(T, L, sc.lightPos, sdir, tstack, bstack, stride, dummy);   // RK:153
+        count_traversal(lane, &s_rays[wave]);
+        float intensity = sc.minIntensity;                                           // RK:165
+        if (sh.tri >= 0) {                                                           // RK:155
+            const v3 hp = add(sc.lightPos, scale(sh.t, sdir));                       // RK:156
+            const v3 dv = sub(hp, ro);                                               // RK:157-159: see light_term (rt_device.h)
+            if (dot(dv, dv) < 0x1.a36e2cp-16f) intensity = pk.template get<4>();
+        }
+        const v3 albedo = V(pk.template get<5>(), pk.template get<6>(), pk.template get<7>());
+        const v3 color = V(pk.template get<0>(), pk.template get<1>(), pk.template get<2>());
+        const v3 blended = scale(intensity, albedo);                                 // RK:135
+        const v3 mixed = divs(add(scale(sum, color), scale(affect, blended)), next); // RK:136
+        pk.template put<0>(mixed.x); pk.template put<1>(mixed.y); pk.template put<2>(mixed.z);
+        rd = V(pk.template get<8>(), pk.template get<9>(), pk.template get<10>());
         affect = affect / 2.0f;                                                      // RK:139
         sum = next;                                                                  // RK:140
     }
-    const uint32_t opix = (by * 8u + row) * A.W + x;
-    // the fog colour is the sky along the primary ray (RK:93-96): its direction is formed again here rather than
-    // carried through both traversals
-    reinterpret_cast<uint32_t*>(A.out)[opix] =
-        compose_pixel_sky(scale(sc.minIntensity, cube_sample<FLAT ? 1 : 0>(A, primary_dir(A, sc, x, y))), color, dist);   // RK:91-98
-    count_rays(A.rays, nrays);
+    v3 color = V(pk.template get<0>(), pk.template get<1>(), pk.template get<2>());
+    const float dist = pk.template get<3>();
+    // One copy of the cube filter: trip 0 (lanes whose path escaped) the sky along the path's last direction, blended into the
+    // running mean (RK:123-125); trip 1 the fog colour, the sky along the primary ray (RK:92) -- its direction is formed again
+    // here rather than carried through the traversals.
+    v3 fog = V(0.0f, 0.0f, 0.0f);
+    v3 dir = V(0.0f, 0.0f, 0.0f);
+    float affect_e = 0.0f, sum_e = 0.0f;
+    if (missed) {
+        dir = V(pk.template get<4>(), pk.template get<5>(), pk.template get<6>());
+        affect_e = pk.template get<7>(); sum_e = pk.template get<8>();
+    }
+    // (the pixel's place is formed again from the lane number, asked of the hardware: nothing of it is carried through the loop)
+    const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t px_e = lane_e & 7u, row_e = lane_e >> 3;
+    if (part < 4u) { px_e = 4u * (part & 1u) + (lane_e & 3u); row_e = 4u * (part >> 1) + (lane_e >> 2); }
+    else if (part >= 16u) { px_e = 2u * (part & 3u) + (lane_e & 1u); row_e = 2u * ((part >> 2) & 3u) + (lane_e >> 1); }
+    const RtFrameArgs& Ae = reread_first_kernarg();
+    const Scene sce = unpack_scene(Ae);
+    const uint32_t x_e = bx * (8u * WAVES) + wave * 8u + px_e;
+    const uint32_t y_e = (Ae.tile_first + by * Ae.tile_step) * 8u + row_e;
+#pragma unroll 1
+    for (int k = missed ? 0 : 1; k < 2; ++k) {
+        if (k == 1) dir = primary_dir(Ae, sce, x_e, y_e);
+        const v3 sky = scale(sce.minIntensity, cube_sample<FLAT ? 1 : 0>(Ae, dir));
+        if (k == 0) color = divs(add(scale(sum_e, color), scale(affect_e, sky)), affect_e + sum_e);   // RK:120, 125
+        else fog = sky;
+    }
+    const uint32_t opix = (by * 8u + row_e) * Ae.W + x_e;
+    reinterpret_cast<uint32_t*>(Ae.out)[opix] = compose_pixel_sky(fog, color, dist);   // RK:91-98
+    if (lane_e == (uint32_t)__builtin_amdgcn_readfirstlane((int)lane_e)) count_wave_rays(Ae.rays, s_rays[wave]);
     // What a tile leaves for the next frame's work list (10 ns ticks) must not depend on how it was rendered, or the list chases
     // its own tail: a whole tile leaves its time; the parts of a split tile leave the LONGEST of theirs, times what a wave of 64
     // diverging lanes takes longer than its slowest sixteenth (3) or quarter (1.5) alone.  Summed, a split tile looked several times
@@ -253,7 +352,7 @@ hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* loo
 // WAVES: one wave per workgroup -- a workgroup's LDS and wave slots come free as soon as its own tile is done
 // (1 / 2 / 4 / 8 waves: 0.545 / 0.571 / 0.603 / 0.624 ms for the 1344x846 frame one at a time, 0.769 / 0.765 /
 // 0.792 / 0.883 ms per 4K frame in flight; profiles/r02/tri_waves.log).
-template <typename STK, int OCC, bool PACKED, int WAVES = 1, bool PAIRS = false, bool P16 = false>
+template <typename STK, int OCC, bool PACKED, int WAVES = 1, bool PAIRS = false, bool P16 = false, int SMALL = 0>
 static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, hipStream_t s) {
     const dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
     const uint32_t n_tiles = grid.x * grid.y;       // trace_triangles decodes the tile itself; with a work list: room for the quarters
@@ -265,8 +364,8 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, 
     const uint32_t padded = grid.x * ((grid.y + 7u) & ~7u);
     const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) + 15u * std::min(n_tiles / 64u, 256u) : (t.xcd_rows ? padded : n_tiles), 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
     if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK, PACKED>), grid, dim3(64 * WAVES), 0, s, a, t);
-    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED, PAIRS, P16>), line, dim3(64 * WAVES), 0, s, a, t);
-    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED, PAIRS, P16>), line, dim3(64 * WAVES), 0, s, a, t);
+    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED, PAIRS, P16, SMALL>), line, dim3(64 * WAVES), 0, s, a, t);
+    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED, PAIRS, P16, SMALL>), line, dim3(64 * WAVES), 0, s, a, t);
 }
 
 hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
@@ -291,7 +390,16 @@ hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int he
 #ifdef RT_TRI_DEV_ENV
     if (const char* e = getenv("RT355_TRI_P16")) p16 = p16 && atoi(e) != 0;
 #endif
-    if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16) launch_tri<uint16_t, 5, true, 1, true, true>(a, t, heatmap, s);
+    uint32_t small = t.tlas_small;
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_SMALL")) small = std::min(small, (uint32_t)atoi(e));
+#endif
+    if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 2u) launch_tri<uint16_t, 6, true, 1, true, true, 2>(a, t, heatmap, s);
+    else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 1u) launch_tri<uint16_t, 5, true, 1, true, true, 1>(a, t, heatmap, s);
+#ifdef RT_TRI_DEV_ENV
+    else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && getenv("RT355_TRI_P16OCC4")) launch_tri<uint16_t, 4, true, 1, true, true>(a, t, heatmap, s);
+#endif
+    else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16) launch_tri<uint16_t, 5, true, 1, true, true>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas) launch_tri<uint16_t, 4, true, 1, true>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u && t.packed_ok) launch_tri<uint16_t, 4, true>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u)           launch_tri<uint16_t, 4, false>(a, t, heatmap, s);
