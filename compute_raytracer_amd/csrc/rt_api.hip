@@ -193,7 +193,7 @@ int rt_create(int device, rt_ctx** out) {
     if (!c) return fail(RT_ERR_HIP, "rt_create: out of host memory");
     c->device = device;
     c->n_cus = (uint32_t)prop.multiProcessorCount;
-    c->wave_slots = (uint32_t)prop.multiProcessorCount * 16u;      // 4 SIMDs x 4 waves of the triangle kernel (launch_tri: OCC)
+    c->wave_slots = (uint32_t)prop.multiProcessorCount * 20u;      // 4 SIMDs x 5 waves: the form of the triangle kernel that awaited frames -- the ones with a work list -- run (rt_launch_triangles)
     hipError_t err;
     err = hipSuccess;
     for (int k = 0; k < kStreams && err == hipSuccess; ++k) err = hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking);
@@ -875,13 +875,14 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         if (order_set >= 0 && c->d_tile_cost[order_set].cap < (size_t)order_n * 4u) {
             // only frames on this stream use the set: wait for them, not for the batch (no slot bookkeeping involved)
             RT_HIP(hipStreamSynchronize(s));
+            const size_t cap = ((size_t)order_n * 4u + 7u) & ~(size_t)7u, scan_bytes = (size_t)rt_order_scan_words() * 4u;
             for (rt_ctx::DevBuf* b : {&c->d_tile_cost[order_set], &c->d_tile_order[order_set]}) {
                 (void)hipFree(b->p);
                 b->p = nullptr; b->cap = 0;
-                RT_HIP(hipMalloc(&b->p, (size_t)order_n * 4u + 8u));       // the list carries two header words
-                b->cap = (size_t)order_n * 4u;
+                RT_HIP(hipMalloc(&b->p, cap + scan_bytes));                // the list carries two header words; behind the costs: order_tiles' bins
+                b->cap = cap;
             }
-            RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));   // tiles leave their times by atomicMax
+            RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, cap + scan_bytes, s));   // tiles leave their times by atomicMax
             c->order_tiles[order_set] = 0;
         }
     }
@@ -903,7 +904,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.n_blas_lookup = c->inst.lookup_on ? (uint32_t)c->inst.lookup.size() : (uint32_t)(c->d_blas_lookup[v].used / 4u);
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
-        ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u;
+        ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u; ts.prio = 0u; ts.in_flight = hint ? 1u : 0u;
         // the top-level tree this frame walks (the mirror holds every node write, per-frame heads included): small enough for the
         // four-slot TLAS stack?  (rt_tlas_fit.h; the same constants as the kernel's: rt_tri_device.h kSmallStack / kSmallNodes)
         ts.tlas_small = 0u;
@@ -945,6 +946,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     if (order_set >= 0) {
         // after the frame's event: rt_wait does not wait for it, the stream's next frame does
         RT_HIP(rt_launch_order_tiles(static_cast<uint32_t*>(c->d_tile_cost[order_set].p),
+                                     reinterpret_cast<uint32_t*>(static_cast<char*>(c->d_tile_cost[order_set].p) + c->d_tile_cost[order_set].cap),
                                      static_cast<uint32_t*>(c->d_tile_order[order_set].p), order_n, c->wave_slots, s));
         c->order_tiles[order_set] = order_n;
     }
@@ -965,6 +967,17 @@ __attribute__((visibility("default"))) int rt_debug_tile_cost(rt_ctx* c, int set
 }
 #endif
 
+// Colour buffer k is about to be written by a frame on stream `st`.  A frame of the current batch that renders into the same
+// buffer on ANOTHER stream must be through first (a streaming read-back of it orders itself: ev_copy).  Streams and buffers
+// rotate independently since awaited frames stay on one stream: within a run of rt_render calls their offset is constant and
+// frame i + 4 follows frame i on its stream anyway, but an awaited frame in between shifts the offset, and rt_render_gather /
+// rt_group_render pair stream k with buffer k whatever rt_render did before.
+int rt_order_colour_buffer(rt_ctx* c, uint32_t k, hipStream_t st) {
+    const int before = c->buf_slot[k];
+    if (before >= 0 && (uint32_t)before < c->in_flight && c->slot_stream[before] != st) RT_HIP(hipStreamWaitEvent(st, c->ev_k1[before], 0));
+    return RT_OK;
+}
+
 int rt_render(rt_ctx* c) {
     if (!c) return fail(RT_ERR_INVALID_ARG, "rt_render: ctx is NULL");
     // consecutive frames rotate over kStreams streams and colour buffers, so that frames enqueued
@@ -976,13 +989,11 @@ int rt_render(rt_ctx* c) {
     // its stream: rotating regardless, that was the frame four steps back, and with the instances turning (the reference's
     // scene spins one of its meshes) a list that old fitted the picture badly: 0.56 ms per frame against 0.38 with nothing
     // moving (profiles/r04/loop_breakdown.log).
-    // (Frames of more than 32,768 tiles keep rotating: order_tiles is one workgroup -- 23 us for the reference's 17,808 tiles,
-    // 174 us for the 129,600 of a 4K frame -- and behind it on the same stream the next frame would wait for it.)
-    const bool big = (size_t)((c->W + 7u) / 8u) * local_tiles(c) > 32768u;
-    if (c->in_flight != 0u || big) c->stream_rot = (c->stream_rot + 1u) % (uint32_t)kStreams;
+    if (c->in_flight != 0u) c->stream_rot = (c->stream_rot + 1u) % (uint32_t)kStreams;
     hipStream_t st = c->streams[c->stream_rot];
     // a streaming read-back (rt_read_pixels_async) may still be copying the frame this buffer holds
     if (c->copy_pending[k]) RT_HIP(hipStreamWaitEvent(st, c->ev_copy[k], 0));
+    { int rc = rt_order_colour_buffer(c, k, st); if (rc != RT_OK) return rc; }
     int rc = rt_enqueue(c, dst, st);
     if (rc == RT_OK) { c->d_out = dst; c->buf_slot[k] = (int)c->in_flight - 1; ++c->frames_rendered; }
     return rc;

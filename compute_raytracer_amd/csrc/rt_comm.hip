@@ -210,9 +210,11 @@ static int render_part(rt_ctx* c, int root, uint32_t k, uint8_t** part) {
     { int rc = ensure_buffers(c, plan.receives); if (rc != RT_OK) return rc; }
     *part = plan.part_in_gather ? s->d_gather[k] + plan.part_offset : c->d_outs[k];
     if (!*part) return fail(RT_ERR_STATE, "rt_render_gather: rt_resize has not been called");
+    if (!plan.part_in_gather) { int rc = rt_order_colour_buffer(c, k, c->streams[k]); if (rc != RT_OK) return rc; }
     int rc = rt_enqueue(c, *part, c->streams[k]);
     if (rc != RT_OK) return rc;
     const uint32_t slot = c->in_flight - 1u;
+    if (!plan.part_in_gather) c->buf_slot[k] = (int)slot;
     RT_HIP(hipEventRecord(s->ev_r1[slot], c->streams[k]));
     s->slot_gathered[slot] = true;
     return RT_OK;

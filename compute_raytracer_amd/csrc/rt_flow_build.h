@@ -1,5 +1,6 @@
-// rt_flow_build.h -- host side of the persistent triangle kernel (rt_flow.hip): the library's own copy of the BLAS
-// trees, relinked.  Host-only, no HIP: tests/c/flow_build_test.cpp compiles it with g++.
+// rt_flow_build.h -- host side of the triangle kernel's PAIRS forms (rt_tri_device.h: trace_blas): the library's own copy of
+// the BLAS trees, relinked.  Host-only, no HIP: tests/c/flow_build_test.cpp compiles it with g++ under ASan + UBSan
+// (tests/test_sanitizers_cpu.py), on trees, one-node buffers and garbage.
 //
 // The reference's traceBLAS (RK:271-330) walks 32-byte nodes {min.xyz, leftChildIndex | max.xyz, primitiveCount}: an inner
 // node (primitiveCount == 0) names its two children by ONE index, they sit side by side at leftChildIndex and
@@ -72,10 +73,15 @@ inline void rt_flow_build(const float* nodes, uint32_t n_nodes, const uint32_t* 
     std::priority_queue<item> heap;
     std::vector<uint8_t> queued(n_nodes, 0);
     int64_t serial = 0;
+    bool wraps = false;
     auto offer = [&](uint32_t parent) {                           // parent: clamped index of a node; queues its children's pair
         out.min_node = std::min(out.min_node, parent);
         const float* p = nodes + 8u * (size_t)parent;
         if (rt_flow_u32f(p[7]) != 0u) return;                     // a leaf has no pair
+        // leftChildIndex = 2^32 - 1 (any f32 >= 4294967040): the reference's `left + 1` wraps to node 0 (RK:277; the node walk
+        // does the same) while every other index beyond the buffer clamps to the last node -- a pair keyed by its clamped left
+        // index cannot tell the two apart.  Such a buffer keeps the node walk.
+        if (rt_flow_u32f(p[3]) == 0xFFFFFFFFu) { wraps = true; return; }
         const uint32_t key = clampi(rt_flow_u32f(p[3]));
         if (queued[key]) return;
         queued[key] = 1;
@@ -99,7 +105,7 @@ inline void rt_flow_build(const float* nodes, uint32_t n_nodes, const uint32_t* 
         offer(b);
     }
     out.n_pairs = (uint32_t)order.size();
-    if (out.n_pairs > 65536u) return;
+    if (out.n_pairs > 65536u || wraps) return;
     out.pairs.assign((size_t)out.n_pairs * 16u, 0.0f);
     for (uint32_t k = 0; k < out.n_pairs; ++k) {
         const uint32_t a = order[k], b = clampi(order[k] + 1u);

@@ -15,18 +15,22 @@ struct RtTriScene {
     uint32_t tlas_small;       // the host walked this frame's top-level tree (rt_tlas_fit.h): 1 = leaves at most 4 levels down, all nodes among
                                // the first 16; 2 = at most 3 levels, 8 nodes, 4 instances; 0 = neither
     uint32_t p16_ok;           // ... and (count << 14 | x) fits 16: leaves of at most 3 triangles, at most 16,384 pair records and lookup slots
-    // Work list (rt_triangles.hip: order_tiles): tile_order[0] tiles are rendered as four quarters, tile_order[1...] is the
-    // order of the tiles (null: every tile whole, in index order); every workgroup adds the time it took to
-    // tile_cost[tile] (null: nowhere), from which the list of the next frame on this stream is made.
+    // Work list (rt_triangles.hip: order_hist / order_scatter): tile_order[0] tiles are rendered as four quarters, tile_order[1] as
+    // sixteen 2x2 blocks, tile_order[2...] is the order of the tiles (null: every tile whole, in index order); every workgroup
+    // leaves the time it took in tile_cost[tile] by atomicMax -- the parts of a split tile: the longest of theirs, scaled (x 3 a
+    // sixteenth, x 1.5 a quarter) -- (null: nowhere), from which the list of the next frame on this stream is made.
     // Relinked copy of the BLAS trees (rt_flow_build.h), when the scene fits it (rt_api.hip: flow_ok; null otherwise): the two
     // children of an inner node as one 64-byte record with packed (count << 16 | x) metas, and per instance the root's meta.
     const float4* pairs;
     uint32_t root_meta[12];    // instances the tile kernel stages (rt_tri_device.h: kLdsBlas)
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    uint32_t in_flight;        // the caller keeps frames in flight (rt_api.hip: pipelined_hint): throughput over latency
+    uint32_t prio;             // development builds: wave priority of the head of the work list (rt_triangles.hip)
     uint32_t xcd_rows;         // set by the launch (no work list): workgroup b renders row (b % 8) + 8 (b / 8 / tiles per row) -- a row per XCD
 };
 
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);
-hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s);
+uint32_t rt_order_scan_words(void);      // words of scan space rt_launch_order_tiles needs, zeroed once (it leaves them zero)
+hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s);
 hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* lookup, uint32_t n_slots, uint32_t n_tri, hipStream_t s);

@@ -118,6 +118,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
         else if ((i -= 16u * s16) < 4u * s4) { tile = list[s16 + (i >> 2)]; part = i & 3u; }
         else if ((i -= 4u * s4) < n_tiles - s16 - s4) tile = list[s16 + s4 + i];
         else return;                                                        // the grid is sized for the most parts there can be
+#ifdef RT_TRI_DEV_ENV
+        if (T.prio >= 1u && part != 4u) __builtin_amdgcn_s_setprio(3);
+        else if (T.prio >= 2u && i < (n_tiles >> 4)) __builtin_amdgcn_s_setprio(2);
+#endif
     } else if (T.xcd_rows != 0u) {
         // Workgroups go to the eight XCDs in turn (b % 8) and each XCD has an L2 of its own: in index order every XCD renders
         // every eighth tile of every row and its L2 holds what the whole band of rows in flight touches.  Here XCD x renders rows
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
 // mean tile 21 us, one in a hundred 156 us, the longest 498 us -- and the 1344x846 frame rendered on its own (the
 // reference's await-each-frame loop) took 504 us: a frame is as long as its longest tile, however empty the chip.  So
 //   * every tile leaves the time it took (tile_cost; the parts of a split tile: the longest of theirs, scaled -- see the kernel's last lines);
-//   * one workgroup turns the costs into the NEXT frame's work list on the same stream: tiles longest first (a counting sort
+//   * two small kernels turn the costs into the NEXT frame's work list on the same stream: tiles longest first (a counting sort
 //     over quarter-octave classes), and the tiles longer than half the frame's throughput time -- sum of all costs / wave
 //     slots / 2 --, at most one in sixteen and 1024 (a quarter-wave for every wave slot of the chip), as four 4x4 quarters each: a quarter of the lanes diverge a quarter as much, and
 //     the frame's longest wave shrinks accordingly; round 4: the tiles longer than TWICE the throughput time, at most one in 64
@@ -248,25 +252,44 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
 //     order[0] = tiles in quarters, order[1] = tiles in sixteenths (the head of the list), order[2...] = the permutation.
 // The picture does not depend on any of it: a pixel is rendered by the same code whatever its turn and company; any
 // array of costs yields a permutation and a split count within the grid's bound.
-__global__ __launch_bounds__(1024) void order_tiles(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, uint32_t wave_slots,
-                                                    uint32_t mult16, uint32_t cap16) {
+// Two launches, many workgroups (round 4's single workgroup took 174 us for the 129,600 tiles of a 4K frame, and awaited 4K
+// frames therefore kept a work list four frames old): order_hist -- every workgroup counts its slice of the costs by class in
+// LDS and adds its counts to the frame's 128 global bins; the workgroup that finishes last turns the bins into the split counts
+// and the classes' first positions --, order_scatter -- every workgroup counts its slice again, reserves a range per class with ONE
+// global atomic per class it holds, and places its tiles.  scan: 264 words behind the costs (rt_order_scan_words), zero between frames.
+constexpr uint32_t kOrderBlock = 256u, kOrderPerThread = 4u;
+__device__ __forceinline__ uint32_t cost_class(uint32_t c) {     // quarter-octave class of a tick count: 0 ... 123, monotone
+    if (c < 4u) return c;
+    const uint32_t e = 31u - (uint32_t)__clz(c);
+    return 4u * e + ((c >> (e - 2u)) & 3u) - 4u;
+}
+__global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __restrict__ cost, uint32_t* __restrict__ scan, uint32_t* __restrict__ order,
+                                                          uint32_t n, uint32_t wave_slots, uint32_t mult16, uint32_t cap16) {
     __shared__ uint32_t bin[128];
     __shared__ unsigned long long total;
+    __shared__ uint32_t last;
     if (threadIdx.x < 128u) bin[threadIdx.x] = 0u;
     if (threadIdx.x == 0u) total = 0ull;
     __syncthreads();
-    auto cls = [](uint32_t c) -> uint32_t {        // quarter-octave class of a tick count: 0 ... 123, monotone
-        if (c < 4u) return c;
-        const uint32_t e = 31u - (uint32_t)__clz(c);
-        return 4u * e + ((c >> (e - 2u)) & 3u) - 4u;
-    };
+    const uint32_t per = kOrderBlock * kOrderPerThread, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     unsigned long long mine = 0ull;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u) { const uint32_t c = cost[i]; mine += c; atomicAdd(&bin[cls(c)], 1u); }
-    atomicAdd(&total, mine);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kOrderBlock) { const uint32_t c = cost[i]; mine += c; atomicAdd(&bin[cost_class(c)], 1u); }
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x < 128u && bin[threadIdx.x]) atomicAdd(&scan[threadIdx.x], bin[threadIdx.x]);
+    if (threadIdx.x == 0u && total) atomicAdd(reinterpret_cast<unsigned long long*>(scan + 128), total);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0u) last = atomicAdd(&scan[130], 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x < 128u) bin[threadIdx.x] = __hip_atomic_load(&scan[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0u) total = __hip_atomic_load(reinterpret_cast<unsigned long long*>(scan + 128), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x == 0u) {                       // exclusive prefix over the classes, longest class first
         const unsigned long long thr = total / (2ull * (wave_slots ? wave_slots : 1u));
-        auto cls_of = [&](unsigned long long v) { return cls(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v); };
+        auto cls_of = [&](unsigned long long v) { return cost_class(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v); };
         const uint32_t kt = cls_of(thr);
         const uint32_t kw = cls_of(4ull * thr);           // twice the throughput time
         const uint32_t k16 = cls_of((unsigned long long)mult16 * thr);          // mult16 / 2 times the throughput time: as sixteenths
@@ -288,9 +311,31 @@ __global__ __launch_bounds__(1024) void order_tiles(uint32_t* __restrict__ cost,
         order[1] = split16;                        // ... behind the tiles rendered as sixteen 2x2 blocks: the head of the list
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
-        order[2u + atomicAdd(&bin[cls(cost[i])], 1u)] = i;
-        cost[i] = 0u;                              // the next frame adds its times up from zero
+    if (threadIdx.x < 128u) { scan[132u + threadIdx.x] = bin[threadIdx.x]; scan[threadIdx.x] = 0u; }   // first positions; bins zero for the next frame
+    if (threadIdx.x < 4u) scan[128u + threadIdx.x] = 0u;                                                // total, ticket
+}
+__global__ __launch_bounds__(kOrderBlock) void order_scatter(uint32_t* __restrict__ cost, uint32_t* __restrict__ scan, uint32_t* __restrict__ order, uint32_t n) {
+    __shared__ uint32_t bin[128], base[128];
+    if (threadIdx.x < 128u) bin[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t per = kOrderBlock * kOrderPerThread, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t cls[kOrderPerThread], at[kOrderPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kOrderPerThread; ++k) {
+        const uint32_t i = lo + threadIdx.x + k * kOrderBlock;
+        cls[k] = i < hi ? cost_class(cost[i]) : 0u;
+        at[k] = i < hi ? atomicAdd(&bin[cls[k]], 1u) : 0u;         // this tile's place among the workgroup's tiles of its class
+    }
+    __syncthreads();
+    if (threadIdx.x < 128u) base[threadIdx.x] = bin[threadIdx.x] ? atomicAdd(&scan[132u + threadIdx.x], bin[threadIdx.x]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kOrderPerThread; ++k) {
+        const uint32_t i = lo + threadIdx.x + k * kOrderBlock;
+        if (i < hi) {
+            order[2u + base[cls[k]] + at[k]] = i;
+            cost[i] = 0u;                              // the next frame records its times from zero
+        }
     }
 }
 
@@ -362,13 +407,21 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, 
     if (const char* e = getenv("RT355_TRI_XCD")) t.xcd_rows = t.xcd_rows && atoi(e) != 0;
 #endif
     const uint32_t padded = grid.x * ((grid.y + 7u) & ~7u);
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_PRIO")) t.prio = (uint32_t)atoi(e);
+    const size_t lds_pad = getenv("RT355_TRI_LDSPAD") ? (size_t)atoi(getenv("RT355_TRI_LDSPAD")) : 0u;
+#else
+    const size_t lds_pad = 0u;
+#endif
     const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) + 15u * std::min(n_tiles / 64u, 256u) : (t.xcd_rows ? padded : n_tiles), 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
     if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK, PACKED>), grid, dim3(64 * WAVES), 0, s, a, t);
-    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED, PAIRS, P16, SMALL>), line, dim3(64 * WAVES), 0, s, a, t);
-    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED, PAIRS, P16, SMALL>), line, dim3(64 * WAVES), 0, s, a, t);
+    else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED, PAIRS, P16, SMALL>), line, dim3(64 * WAVES), lds_pad, s, a, t);
+    else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED, PAIRS, P16, SMALL>), line, dim3(64 * WAVES), lds_pad, s, a, t);
 }
 
-hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
+uint32_t rt_order_scan_words(void) { return 264u; }
+
+hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
     // Sixteenths from twice the throughput time on, at most 64 tiles (1 / 2 / 4 / 8 times: REF 0.459 / 0.449 / 0.537 / 0.539 ms one at a
     // time, TRI 0.255 / 0.256 / 0.291 / 0.372; 64 against 256 tiles: REF 0.449 against 0.465; a third level of single pixels
@@ -377,8 +430,11 @@ hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* order, uint32_t n_til
 #ifdef RT_TRI_DEV_ENV
     if (const char* e = getenv("RT355_TRI_MULT16")) mult16 = (uint32_t)atoi(e);
     if (const char* e = getenv("RT355_TRI_CAP16")) cap16 = std::min(256u, (uint32_t)atoi(e));
+    if (const char* e = getenv("RT355_TRI_SLOTS")) wave_slots = (uint32_t)atoi(e);
 #endif
-    hipLaunchKernelGGL(rtk::order_tiles, dim3(1), dim3(1024), 0, s, cost, order, n_tiles, wave_slots, mult16, cap16);
+    const uint32_t per = rtk::kOrderBlock * rtk::kOrderPerThread, blocks = (n_tiles + per - 1u) / per;
+    hipLaunchKernelGGL(rtk::order_hist, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles, wave_slots, mult16, cap16);
+    hipLaunchKernelGGL(rtk::order_scatter, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles);
     return hipGetLastError();
 }
 
@@ -390,8 +446,13 @@ hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int he
 #ifdef RT_TRI_DEV_ENV
     if (const char* e = getenv("RT355_TRI_P16")) p16 = p16 && atoi(e) != 0;
 #endif
+    // Six waves per SIMD (the tiny form) for a caller that keeps frames in flight -- throughput: REF 0.215 -> 0.208 ms per frame,
+    // TRI4K 0.542 -> 0.517 --, five (the small form) for one that awaits every frame: such a frame is as long as its longest
+    // waves, and those run faster in less company (REF 0.37 against 0.42-0.53 ms; profiles/r05/tri_forms.log).
     uint32_t small = t.tlas_small;
+    if (small == 2u && !t.in_flight) small = 1u;
 #ifdef RT_TRI_DEV_ENV
+    if (getenv("RT355_TRI_SMALL")) small = t.tlas_small;
     if (const char* e = getenv("RT355_TRI_SMALL")) small = std::min(small, (uint32_t)atoi(e));
 #endif
     if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 2u) launch_tri<uint16_t, 6, true, 1, true, true, 2>(a, t, heatmap, s);

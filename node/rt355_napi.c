@@ -467,7 +467,13 @@ static napi_value DestroyGroup(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 1, argv)) return NULL;
     handle* h = get_handle(env, argv[0], 1);
     if (!h) return NULL;
+    /* the members' pending read-backs end with the group: rt_group_destroy waits for the copies, the arrays are released here */
+    rt_ctx* members[64];
+    int n = h->group ? rt_group_size(h->group) : 0;
+    if (n > 64) n = 64;
+    for (int i = 0; i < n; ++i) members[i] = rt_group_ctx(h->group, i);
     rt_group_destroy(h->group);
+    for (int i = 0; i < n; ++i) if (members[i]) release_pending(env, members[i]);
     h->group = NULL;      /* member handles check the context pointer the group hands out: see GroupCtx */
     return undefined(env);
 }
@@ -586,16 +592,24 @@ static napi_value HostAlloc(napi_env env, napi_callback_info info) {
 
 /* Destinations of copies that have been begun and not yet awaited: the addon holds a reference to each array, so that a
  * script that drops its own cannot have the (pinned) memory freed under a running DMA; readPixelsWait releases them. */
+/* The table belongs to the environment that loaded the addon (napi_set_instance_data in Init): a reference is deleted with
+ * the napi_env it was created with, also when worker threads load the addon a second time. */
 #define PENDING_MAX 64
-static struct { napi_ref ref; rt_ctx* ctx; } g_pending[PENDING_MAX];
-static int g_pending_n = 0;
+typedef struct pending_table { struct { napi_ref ref; rt_ctx* ctx; } e[PENDING_MAX]; int n; } pending_table;
+static pending_table* pending_of(napi_env env) {
+    void* p = NULL;
+    return napi_get_instance_data(env, &p) == napi_ok ? (pending_table*)p : NULL;
+}
+static void free_pending_table(napi_env env, void* data, void* hint) { (void)env; (void)hint; free(data); }
 static void release_pending(napi_env env, rt_ctx* ctx) {
+    pending_table* t = pending_of(env);
+    if (!t) return;
     int k = 0;
-    for (int i = 0; i < g_pending_n; ++i) {
-        if (g_pending[i].ctx == ctx) napi_delete_reference(env, g_pending[i].ref);
-        else g_pending[k++] = g_pending[i];
+    for (int i = 0; i < t->n; ++i) {
+        if (t->e[i].ctx == ctx) napi_delete_reference(env, t->e[i].ref);
+        else t->e[k++] = t->e[i];
     }
-    g_pending_n = k;
+    t->n = k;
 }
 
 /* readPixelsAsync(ctx, framesBack, Uint8Array): the copy runs beside the rendering of the next frames; the array stays
@@ -607,17 +621,19 @@ static napi_value ReadPixelsAsync(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 3, argv)) return NULL;
     rt_ctx* ctx = get_ctx(env, argv[0]);
     if (!ctx || !get_u32(env, argv[1], &back) || !get_typed(env, argv[2], napi_uint8_array, &data, &len)) return NULL;
-    if (g_pending_n == PENDING_MAX) {          /* more copies begun than anybody awaits: complete this context's, then go on */
+    pending_table* t = pending_of(env);
+    if (!t) { napi_throw_error(env, NULL, "rt355: no instance data"); return NULL; }
+    if (t->n == PENDING_MAX) {                 /* more copies begun than anybody awaits: complete this context's, then go on */
         int rcw = rt_read_pixels_wait(ctx);
         if (rcw != RT_OK) return throw_status(env, rcw, ctx);
         release_pending(env, ctx);
-        if (g_pending_n == PENDING_MAX) { napi_throw_error(env, NULL, "rt355: too many read-backs pending on other contexts"); return NULL; }
+        if (t->n == PENDING_MAX) { napi_throw_error(env, NULL, "rt355: too many read-backs pending on other contexts"); return NULL; }
     }
     napi_ref ref;
     if (napi_create_reference(env, argv[2], 1, &ref) != napi_ok) { napi_throw_error(env, NULL, "rt355: cannot reference the destination"); return NULL; }
     int rc = rt_read_pixels_async(ctx, back, (uint8_t*)data, len);
     if (rc != RT_OK) { napi_delete_reference(env, ref); return throw_status(env, rc, ctx); }
-    g_pending[g_pending_n].ref = ref; g_pending[g_pending_n].ctx = ctx; ++g_pending_n;
+    t->e[t->n].ref = ref; t->e[t->n].ctx = ctx; ++t->n;
     return undefined(env);
 }
 
@@ -665,6 +681,12 @@ static napi_value AbiVersion(napi_env env, napi_callback_info info) {
 }
 
 static napi_value Init(napi_env env, napi_value exports) {
+    pending_table* table = (pending_table*)calloc(1, sizeof(pending_table));
+    if (!table || napi_set_instance_data(env, table, free_pending_table, NULL) != napi_ok) {
+        free(table);
+        napi_throw_error(env, NULL, "rt355: cannot set instance data");
+        return NULL;
+    }
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"create", Create}, {"destroy", Destroy}, {"resize", Resize}, {"writeParams", WriteParams},
         {"writeSpheres", WriteSpheres}, {"writeCubemapFace", WriteCubemapFace}, {"selectKernel", SelectKernel},

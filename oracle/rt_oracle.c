@@ -75,7 +75,10 @@ typedef struct {
 static render_state trace_tlas(const rt_oracle_tri_scene* T, v3 o, v3 d, uint32_t* steps);
 static void tri_work_flush(void);
 /* measurement only (rt_oracle_tri_trace_px): the sequence of traversal steps of the current pixel, one byte each */
-static uint64_t g_sp_hist[2][24];   /* measurement only: pushes by stack slot, [0] BLAS [1] TLAS (racy under OpenMP; use 1 thread) */
+/* measurement only (rt_oracle_tri_sp_hist): pushes by stack slot, [0] BLAS [1] TLAS -- per thread, folded into the totals with
+ * the work counters (tri_work_flush): nothing shared is written from the traversal loops of an OpenMP render */
+static __thread uint64_t tl_sp_hist[2][24];
+static uint64_t g_sp_hist[2][24];
 static uint32_t* g_node_hist;   /* measurement only: visits per inner BLAS node (single-threaded use) */
 static __thread uint8_t* tl_trace; static __thread size_t tl_trace_n, tl_trace_cap;
 static inline void trace_code(uint8_t c) { if (tl_trace) { if (tl_trace_n < tl_trace_cap) tl_trace[tl_trace_n] = c; ++tl_trace_n; } }
@@ -525,6 +528,11 @@ static void tri_work_flush(void) {
         if (tl_tri_work[k]) __atomic_fetch_add(&g_tri_work[k], tl_tri_work[k], __ATOMIC_RELAXED);
         tl_tri_work[k] = 0;
     }
+    for (int k = 0; k < 48; ++k) {
+        uint64_t* t = &tl_sp_hist[0][0] + k;
+        if (*t) __atomic_fetch_add(&g_sp_hist[0][0] + k, *t, __ATOMIC_RELAXED);
+        *t = 0;
+    }
 }
 void rt_oracle_tri_counters(uint64_t out[3]) {
     tri_work_flush();
@@ -640,7 +648,7 @@ static render_state trace_blas(const rt_oracle_tri_scene* T, v3 o, v3 d, const f
                 node = load_node(T, iChild1);                                    /* RK:302 */
                 if (distance2 < blasNearestHit) {                                /* RK:303 */
                     stack[sclamp(stackLocation)] = iChild2;                      /* RK:304 (no overflow guard) */
-                    g_sp_hist[0][stackLocation < 23u ? stackLocation : 23u] += 1;
+                    tl_sp_hist[0][stackLocation < 23u ? stackLocation : 23u] += 1;
                     stackLocation += 1;
                 }
             }
@@ -702,7 +710,7 @@ static render_state trace_tlas(const rt_oracle_tri_scene* T, v3 o, v3 d, uint32_
                 node = load_node(T, iChild1);                                    /* RK:208 */
                 if (distance2 < nearestHit) {                                    /* RK:209 */
                     stack[sclamp(stackLocation)] = iChild2;
-                    g_sp_hist[1][stackLocation < 23u ? stackLocation : 23u] += 1;
+                    tl_sp_hist[1][stackLocation < 23u ? stackLocation : 23u] += 1;
                     stackLocation += 1;
                     /* RK:212-214 guards with `>`; the heatmap twin (steps != NULL) with `>=`, HK:168 */
                     if (steps ? stackLocation >= STACK_SIZE : stackLocation > STACK_SIZE) stackLocation = STACK_SIZE - 1u;
@@ -777,7 +785,7 @@ int rt_oracle_tri_work_px(const float params[24], const rt_oracle_tri_scene* tri
 /* Measurement only (tools/tri_sched_sim.py): the step sequence of every pixel's path, one byte per step -- 'n' TLAS inner
  * node, 'I' instance entered, 'N' BLAS inner node, 'T' triangle test, 'R' / 'S' reflection / shadow ray complete --,
  * pixel p's steps at codes[offsets[p] .. offsets[p+1]).  Returns the number of bytes needed (codes may be too small). */
-void rt_oracle_tri_sp_hist(uint64_t out[48]) { memcpy(out, g_sp_hist, sizeof g_sp_hist); memset(g_sp_hist, 0, sizeof g_sp_hist); }
+void rt_oracle_tri_sp_hist(uint64_t out[48]) { tri_work_flush(); memcpy(out, g_sp_hist, sizeof g_sp_hist); memset(g_sp_hist, 0, sizeof g_sp_hist); }
 void rt_oracle_tri_node_hist(uint32_t* hist) { g_node_hist = hist; }   /* hist[left child index] += 1 per inner-node visit; NULL: off */
 
 uint64_t rt_oracle_tri_trace_px(const float params[24], const rt_oracle_tri_scene* tri, const rt_oracle_face faces[6],

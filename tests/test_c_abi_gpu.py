@@ -36,7 +36,7 @@ def test_plain_c_host(tmp_path, oracle, strict):
     ref, _, rays = oracle.render(p, s, sky.faces, W, H)
     got = np.fromfile(out, dtype=np.uint8).reshape(H, W, 4)
     assert np.array_equal(got, ref)
-    assert "rays=%d " % rays in r.stdout and "abi=3" in r.stdout
+    assert "rays=%d " % rays in r.stdout and "abi=4" in r.stdout
 
 
 def _build(tmp_path, name):
