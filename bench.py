@@ -84,6 +84,10 @@ def parse():
                     help="N > 1: tiles go to rank 0 only (grouped ncclSend/ncclRecv) or to every rank (ncclAllGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of K steps is run this many times in the one invocation: ms_per_step / value are the FIRST "
+                         "region's (the contract's K steps), ms_per_step_median / _min are taken over all of them")
+    ap.add_argument("--no-node", action="store_true", help="skip the measurement through the Node host (node/bench-frames.js)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="--gpus N > 1 without a launcher: print the torch.distributed.run command the ranks would be started with, and exit")
     ap.add_argument("--force-dist", action="store_true",
@@ -155,6 +159,87 @@ def cpu_baseline_tri(cfg, scene, mat, sky, target_s, gpu_frame):
         "per_ray": {"node_loads_32B": nodes / max(rays, 1), "triangle_tests_48B": tests / max(rays, 1), "instance_records_80B": blas / max(rays, 1)},
         "gpu_rows_match": bool(np.array_equal(gpu_frame[rows], img[rows])) if gpu_frame is not None else None,
     }
+
+
+def gpu_clocks():
+    """The clock state of the GPU the line was measured on, asked of amd-smi (rocm-smi if that fails) in a child
+    process: current / maximum shader and memory clocks and the performance level, whatever the tool reports of them."""
+    import subprocess
+    for cmd in (["amd-smi", "metric", "--clock", "--json"], ["rocm-smi", "--showclocks", "--showperflevel", "--json"]):
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=30)
+            if out.returncode != 0 or not out.stdout.strip():
+                continue
+            starts = [i for i in (out.stdout.find("{"), out.stdout.find("[")) if i >= 0]
+            doc = json.loads(out.stdout[min(starts):])
+            found = {}
+            def walk(o, path):
+                if isinstance(o, dict):
+                    for k, v in o.items():
+                        walk(v, path + [str(k)])
+                elif isinstance(o, list):
+                    for i, v in enumerate(o[:1]):          # the first GPU: the one rank 0 measures on
+                        walk(v, path)
+                else:
+                    key = "/".join(path).lower()
+                    if any(w in key for w in ("gfx_0", "gfx/", "sclk", "mem_0", "mclk", "perf", "fclk")) and len(found) < 24:
+                        found["/".join(path)] = o
+            walk(doc, [])
+            return {"tool": " ".join(cmd), "values": found}
+        except Exception:
+            continue
+    return None
+
+
+def node_bench(name, scene, mat, sky, cfg, frames):
+    """The same workload through the Node host (node/bench-frames.js: Node-12 CommonJS scene layer -> N-API addon -> C ABI), in a
+    fresh child process -- never an exec; the parent's context is idle meanwhile.  C3: the scene comes from the Node layer's own
+    generator; REF: the packed upload buffers are handed over as files.  -> the child's JSON line, or {"skipped": why}."""
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "node", "rt355.node")
+    if not node or not os.path.exists(addon):
+        return {"skipped": "no node binary" if not node else "node/rt355.node not built"}
+    tmp = None
+    try:
+        if name in ("C3", "C2", "C1"):
+            arg = name
+        else:
+            import numpy as np
+            tmp = tempfile.mkdtemp(prefix="rt355_node_")
+            f = lambda a: [float(v) for v in np.asarray(a).reshape(-1)]
+            sky_file = os.path.join(tmp, "sky.rgba")
+            with open(sky_file, "wb") as fh:
+                for face in sky.faces:
+                    fh.write(np.ascontiguousarray(face, dtype=np.uint8).tobytes())
+            doc = {"width": cfg["width"], "height": cfg["height"], "bounces": cfg["bounces"], "tlasNodesMax": scene.tlasNodesMax,
+                   "camera": {"position": f(scene.camera.position), "forwards": f(scene.camera.forwards),
+                              "right": f(scene.camera.right), "up": f(scene.camera.up)},
+                   "light": {"position": f(scene.light.position), "lightIntensity": scene.light.lightIntensity,
+                             "minIntensity": scene.light.minIntensity},
+                   "packed": {"triangleData": f(scene.pack_triangles()), "nodeDataB": f(scene.pack_blas_nodes()),
+                              "triangleIndexData": f(scene.pack_tri_lookup())},
+                   "frame": {"blasData": f(scene.pack_blas()), "blasIndexData": f(scene.pack_blas_lookup()),
+                             "nodeDataA": f(scene.pack_tlas_nodes())},
+                   "meshTexture": {"width": int(mat.image.shape[1]), "height": int(mat.image.shape[0]), "data": mat.image.reshape(-1).tolist()}}
+            if sky.faces[0].shape[0] > 1:
+                doc["sky"] = {"size": int(sky.faces[0].shape[0]), "file": sky_file}
+            arg = os.path.join(tmp, "scene.json")
+            json.dump(doc, open(arg, "w"))
+        env = dict(os.environ)
+        env.pop("GPU_MAX_HW_QUEUES", None)       # the library's own default is what a Node host gets (rt_create)
+        out = subprocess.run([node, os.path.join(ROOT, "node", "bench-frames.js"), arg, str(frames)], capture_output=True, text=True,
+                             timeout=600, env=env, cwd=ROOT)
+        if out.returncode != 0:
+            return {"skipped": "node/bench-frames.js failed: " + out.stderr.strip()[-300:]}
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:                       # the Node figure is an extra: its absence must not cost the line
+        return {"skipped": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        if tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def kernel_label(kernel_id):
@@ -326,7 +411,9 @@ def main():
     fence()
     for _ in range(a.warmup):
         step(a.serial)
-    elapsed, kms, gms, kframes = timed(a.steps, a.serial)
+    regions = [timed(a.steps, a.serial) for _ in range(max(1, a.repeats))]      # every region: exactly K steps between two fences
+    elapsed, kms, gms, kframes = regions[0]
+    region_ms = [e / a.steps * 1e3 for (e, _, _, _) in regions]
     rays_local = r.stats()["rays"]
     kid_main = r.stats()["kernel_id"]                 # the form the timed frames ran as
     if a.serial:                      # every rt_wait reports its own batch of one: sample the per-frame times afterwards
@@ -349,13 +436,15 @@ def main():
     # one frame at a time, separately timed
     ssteps = min(a.steps, 20) if a.serial_steps < 0 else a.serial_steps
     serial_ms = None
+    serial_regions = None
     if a.serial:
         serial_ms = elapsed / a.steps * 1e3
+        serial_regions = region_ms
     elif ssteps > 0:
         step(True)                    # untimed: the library sizes a frame's grid by how the caller has been enqueuing
         step(True)
-        s_elapsed, _, _, _ = timed(ssteps, True)
-        serial_ms = s_elapsed / ssteps * 1e3
+        serial_regions = [timed(ssteps, True)[0] / ssteps * 1e3 for _ in range(max(1, a.repeats))]
+        serial_ms = serial_regions[0]
     kid_serial = r.stats()["kernel_id"]
 
     # what a host that READS every frame gets (render, wait, copy the frame to pageable host memory: the PCIe-inclusive
@@ -427,8 +516,8 @@ def main():
             scene.buildTopLevel()
 
     if multi:
-        t = torch.tensor([elapsed, float(rays_local), kms / max(kframes, 1), gms / max(kframes, 1), serial_ms or 0.0],
-                         dtype=torch.float64)
+        t = torch.tensor([elapsed, float(rays_local), kms / max(kframes, 1), gms / max(kframes, 1), serial_ms or 0.0] + region_ms +
+                         (serial_regions or []), dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -438,6 +527,9 @@ def main():
         kernel_ms = float(tmax[2])            # slowest rank's average render time
         gather_ms = float(tmax[3])
         serial_ms = float(tmax[4]) if serial_ms is not None else None
+        region_ms = [float(v) for v in tmax[5:5 + len(region_ms)]]             # every region: the slowest rank's time
+        if serial_regions:
+            serial_regions = [float(v) for v in tmax[5 + len(region_ms):]]
         rays_kernel = rays_frame / world      # average rays per launch
     else:
         rays_frame = rays_local
@@ -570,6 +662,11 @@ def main():
                       ("Mrays/s at %dx%d, %d spheres, %d bounces" % (W, H, N, B)),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "frames_per_s": 1e3 / ms_per_step,
+            # the same K steps timed `repeats` times in this invocation (the first is ms_per_step): how far one region is from another
+            "repeats": len(region_ms), "ms_per_step_median": sorted(region_ms)[len(region_ms) // 2], "ms_per_step_min": min(region_ms),
+            "ms_per_step_all": region_ms,
+            "serial_ms_per_step_median": sorted(serial_regions)[len(serial_regions) // 2] if serial_regions else None,
+            "serial_ms_per_step_min": min(serial_regions) if serial_regions else None,
             # what a caller gets, by how it calls: the reference's loop awaits every frame (RR:467) = serial; a host that also
             # copies every frame out pays the PCIe read-back; `value` / ms_per_step are frames enqueued back to back
             "serial_ms_per_step": serial_ms,
@@ -610,6 +707,17 @@ def main():
                                "figure; DESIGN.md 6 gives the emulated per-rank times for both." % FLIGHT)
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        out["clocks"] = gpu_clocks()
+        # the drop-in in the reference's host language, same workload (C3 and the reference's own scene)
+        if not multi and not a.no_node and a.mode == "fast" and a.variant == 0 and name in ("C3", "REF"):
+            nb = node_bench(name, scene, mat, sky, cfg, min(a.steps, 100))
+            out["node"] = nb
+            out["node_loop_ms_per_step"] = nb.get("awaitedMsPerFrame")            # `await renderer.render()` per frame (src/app.ts:124-127)
+            out["node_inflight_ms_per_step"] = nb.get("inflightMsPerFrame")       # rt.render back to back, one await per batch
+            out["node_streamed_readback_ms_per_step"] = nb.get("streamedMsPerFrame")
+            if nb.get("sha256") and check and "sha256_matches_oracle_frame" in check:
+                gold_sha = (golden_frame(name) or {}).get("sha256") if not tri else json.load(open(os.path.join(ROOT, "tests", "golden", "ref_pin.json")))["oracle_frame_sha256_white_texture"]
+                out["node"]["frame_matches_oracle"] = nb["sha256"] == gold_sha
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

@@ -170,9 +170,23 @@ const char* rt_kernel_name(int id) {
 
 const char* rt_last_error(rt_ctx*) { return g_rt_err.c_str(); }
 
+// A context keeps four frames in flight on four streams, next to its copy stream and RCCL's: with the HIP runtime's default of
+// four hardware queues per device several of them share a queue and serialise (C3 through the N > 1 path: 3.67 instead of
+// 2.43 ms per frame, round 2).  The runtime reads GPU_MAX_HW_QUEUES once, when it initialises -- at the process's first HIP
+// call --, so the library asks for eight before ITS first HIP call, unless the host has set the variable itself
+// (RT355_KEEP_HW_QUEUES=1: leave the runtime's default alone).  A host that has initialised HIP before it creates its first
+// context keeps what its runtime read then.
+void rt_default_hw_queues(void) {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (!getenv("RT355_KEEP_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 int rt_create(int device, rt_ctx** out) {
     if (!out) return fail(RT_ERR_INVALID_ARG, "rt_create: out is NULL");
     *out = nullptr;
+    rt_default_hw_queues();
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {

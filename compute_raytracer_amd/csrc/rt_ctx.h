@@ -149,6 +149,7 @@ struct rt_ctx {
 extern "C" {
 RT_INTERNAL int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s);   // prep + ray-trace launches of one frame into `dst` on `s`
 RT_INTERNAL int rt_order_colour_buffer(rt_ctx* c, uint32_t k, hipStream_t st);   // before a frame on `st` writes colour buffer k
+RT_INTERNAL void rt_default_hw_queues(void);                          // GPU_MAX_HW_QUEUES=8 unless the host set it: before the first HIP call
 RT_INTERNAL int rt_drain(rt_ctx* c);                                  // waits for the frames in flight
 RT_INTERNAL uint32_t rt_local_tiles(const rt_ctx* c);
 RT_INTERNAL void rt_abandon_in_flight(rt_ctx* c);                     // after a communicator abort: forget the frames in flight
