@@ -441,8 +441,8 @@ def main():
         serial_ms = elapsed / a.steps * 1e3
         serial_regions = region_ms
     elif ssteps > 0:
-        step(True)                    # untimed: the library sizes a frame's grid by how the caller has been enqueuing
-        step(True)
+        for _ in range(8):            # untimed: the library sizes a frame's grid by how the caller has been enqueuing, and the
+            step(True)                # triangle kernel's work list is made from the previous awaited frame on the same stream
         serial_regions = [timed(ssteps, True)[0] / ssteps * 1e3 for _ in range(max(1, a.repeats))]
         serial_ms = serial_regions[0]
     kid_serial = r.stats()["kernel_id"]

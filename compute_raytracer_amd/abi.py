@@ -49,7 +49,7 @@ class RtStats(ctypes.Structure):
         ("batch_frames", ctypes.c_uint32), ("batch_kernel_ms", ctypes.c_float),
         ("gather_ms", ctypes.c_float), ("batch_gather_ms", ctypes.c_float),
         ("kernel_id", ctypes.c_uint32), ("grid_share", ctypes.c_uint32), ("instance_uploads", ctypes.c_uint32),
-        ("pair_rebuilds", ctypes.c_uint32),
+        ("tri_form", ctypes.c_uint32), ("pair_rebuilds", ctypes.c_uint32),
     ]
 
 

@@ -21,6 +21,7 @@
 
 thread_local std::string g_rt_err;
 thread_local int g_rt_kernel_id = 0;
+thread_local int g_rt_tri_form = 0;
 
 #ifndef RT355_BUILD_ID
 #define RT355_BUILD_ID "unknown"
@@ -965,6 +966,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         c->order_tiles[order_set] = order_n;
     }
     c->stats.kernel_id = (uint32_t)g_rt_kernel_id;
+    if (tri) c->stats.tri_form = (uint32_t)g_rt_tri_form;
     c->stats.grid_share = fa.grid_share;
     c->in_flight = slot + 1;
     return RT_OK;
@@ -1009,6 +1011,20 @@ int rt_render(rt_ctx* c) {
     if (c->copy_pending[k]) RT_HIP(hipStreamWaitEvent(st, c->ev_copy[k], 0));
     { int rc = rt_order_colour_buffer(c, k, st); if (rc != RT_OK) return rc; }
     int rc = rt_enqueue(c, dst, st);
+#ifdef RT355_DEV_EXPORTS
+    // development builds (tools/root_probe.py): what the ROOT of a group of RT355_DEV_ROOT_WORLD ranks runs behind its share of the
+    // frame -- the de-interleave of the whole gathered frame, on the frame's own stream, moving its end event as rt_render_gather does
+    if (rc == RT_OK)
+        if (const char* e = getenv("RT355_DEV_ROOT_WORLD")) {
+            static uint8_t* dev_gather[kStreams] = {nullptr};
+            static uint8_t* dev_frame[kStreams] = {nullptr};
+            const uint32_t world = (uint32_t)atoi(e);
+            const size_t gb = (size_t)world * rt_padded_tiles(c->H, world) * 8u * c->W * 4u, fb = (size_t)c->H * c->W * 4u;
+            if (!dev_gather[k]) { RT_HIP(hipMalloc(reinterpret_cast<void**>(&dev_gather[k]), gb)); RT_HIP(hipMalloc(reinterpret_cast<void**>(&dev_frame[k]), fb)); }
+            RT_HIP(rt_launch_assemble(dev_gather[k], dev_frame[k], c->W, c->H, world, rt_padded_tiles(c->H, world), st));
+            RT_HIP(hipEventRecord(c->ev_k1[c->in_flight - 1u], st));
+        }
+#endif
     if (rc == RT_OK) { c->d_out = dst; c->buf_slot[k] = (int)c->in_flight - 1; ++c->frames_rendered; }
     return rc;
 }

@@ -37,7 +37,6 @@ struct rt_comm_state {
     size_t gather_bytes = 0, frame_bytes = 0;
     int latest = -1;                       // buffer set of the latest rt_render_gather (-1: none yet)
     bool latest_has_frame = false;         // this rank received that frame
-    bool assembled[kStreams] = {false};    // d_frame[k] holds the de-interleaved frame of the set's latest exchange (rt_frame_pixels)
     hipEvent_t ev_r1[RT355_MAX_IN_FLIGHT] = {nullptr};   // end of the render, before the exchange
     hipEvent_t ev_x1[RT355_MAX_IN_FLIGHT] = {nullptr};   // end of the exchange, before the de-interleave
     bool slot_gathered[RT355_MAX_IN_FLIGHT] = {false};
@@ -252,12 +251,14 @@ static int finish_part(rt_ctx* c, int root, uint32_t k, uint8_t* part) {
     const bool receives = root < 0 || (uint32_t)root == c->rank;
     hipStream_t st = c->streams[k];
     RT_HIP(hipEventRecord(s->ev_x1[c->in_flight - 1u], st));
-    // The gathered tiles stay as they arrived ([rank][tile][8][W][4]): a host that reads the frame gets it de-interleaved by the
-    // copy itself (rt_read_frame: one 2-D copy per rank), a device consumer by a kernel when it asks (rt_frame_pixels).  Round 4
-    // ran that kernel here, behind every exchange: 33 MB read and written per C3 frame on the GPU that also renders its share --
-    // the root of eight at a 0.23 ms period (profiles/r05/root_probe.log).
-    s->assembled[k] = false;
-    // the frame is complete when the exchange is: move the slot's end event
+    // The de-interleave of the whole frame on the GPU that also renders its share: priced as the root of eight on one GPU
+    // (tools/root_probe.py, profiles/r05/root_probe.log) -- 66 MB of HBM traffic per C3 frame, behind the exchange on the frame's
+    // own stream while three other frames render: +0.004 ms on the frame period.  Taking it off the device (one 2-D copy per rank
+    // in rt_read_frame) was built and measured too: the copies are PCIe-bound either way, and eight strided ones are slower than
+    // this kernel + one linear copy (0.667 against 0.589 ms per frame read).  So it stays here.
+    if (receives)
+        RT_HIP(rt_launch_assemble(s->d_gather[k], s->d_frame[k], c->W, c->H, c->world, rt_padded_tiles(c->H, c->world), st));
+    // the frame is complete when the exchange and the de-interleave are: move the slot's end event
     RT_HIP(hipEventRecord(c->ev_k1[c->in_flight - 1u], st));
     s->latest = (int)k;
     s->latest_has_frame = receives;
@@ -365,51 +366,19 @@ int rt_frame_pixels(rt_ctx* c, void** out_ptr, size_t* out_bytes) {
     if (!c->comm->latest_has_frame) return fail(RT_ERR_STATE, "rt_frame_pixels: this rank did not receive the frame (it is not the root)");
     if (c->comm->latest_w != c->W || c->comm->latest_h != c->H || (size_t)c->H * c->W * 4u > c->comm->frame_bytes)
         return fail(RT_ERR_STATE, "rt_frame_pixels: the target was resized after the latest rt_render_gather");
-    // the de-interleave kernel runs when a device consumer asks for the frame, once per frame: behind the frame on its stream,
-    // and complete when this call returns
-    rt_comm_state* s = c->comm;
-    const int k = s->latest;
-    if (!s->assembled[k]) {
-        RT_HIP(hipSetDevice(c->device));
-        { int rc = rt_wait(c); if (rc != RT_OK) return rc; }
-        RT_HIP(rt_launch_assemble(s->d_gather[k], s->d_frame[k], c->W, c->H, c->world, rt_padded_tiles(c->H, c->world), c->streams[k]));
-        RT_HIP(hipStreamSynchronize(c->streams[k]));
-        s->assembled[k] = true;
-    }
-    *out_ptr = s->d_frame[k];
+    *out_ptr = c->comm->d_frame[c->comm->latest];
     *out_bytes = (size_t)c->H * c->W * 4u;
     return RT_OK;
 }
 
 int rt_read_frame(rt_ctx* c, uint8_t* dst, size_t cap) {
     if (!c || !dst) return fail(RT_ERR_INVALID_ARG, "rt_read_frame: NULL argument");
-    if (!c->comm || c->comm->latest < 0) return fail(RT_ERR_STATE, "rt_read_frame: no rt_render_gather yet");
-    rt_comm_state* s = c->comm;
-    if (!s->latest_has_frame) return fail(RT_ERR_STATE, "rt_read_frame: this rank did not receive the frame (it is not the root)");
-    if (s->latest_w != c->W || s->latest_h != c->H || (size_t)c->H * c->W * 4u > s->frame_bytes)
-        return fail(RT_ERR_STATE, "rt_read_frame: the target was resized after the latest rt_render_gather");
-    const size_t bytes = (size_t)c->H * c->W * 4u;
+    void* p = nullptr;
+    size_t bytes = 0;
+    { int rc = rt_frame_pixels(c, &p, &bytes); if (rc != RT_OK) return rc; }
     if (cap < bytes) return fail(RT_ERR_CAPACITY, "rt_read_frame: destination smaller than W*H*4");
-    RT_HIP(hipSetDevice(c->device));
     { int rc = rt_wait(c); if (rc != RT_OK) return rc; }
-    // Tile t of the frame is tile t / world of rank t % world (rt_exchange_plan.h: rt_gathered_tile_offset): rank q's tiles are
-    // rows of 8 * W * 4 bytes, side by side in the gather buffer and `world` rows apart in the frame -- a 2-D copy per rank
-    // (source pitch = one tile, destination pitch = world tiles).  The frame's last tile may be short: it goes by itself.
-    const uint8_t* g = s->d_gather[s->latest];
-    const size_t tile = (size_t)8u * c->W * 4u, msg = rt_plan_message_bytes(c->W, c->H, c->world);
-    const uint32_t T = rt_plan_tiles_total(c->H), last_rows = c->H - 8u * (T - 1u);
-    for (uint32_t q = 0; q < c->world; ++q) {
-        uint32_t n = rt_plan_tiles_of_rank(c->H, q, c->world);
-        if (n == 0u) continue;
-        const bool has_last = (T - 1u) % c->world == q;
-        const uint32_t full = (has_last && last_rows != 8u) ? n - 1u : n;
-        if (full)
-            RT_HIP(hipMemcpy2DAsync(dst + (size_t)q * tile, (size_t)c->world * tile, g + (size_t)q * msg, tile, tile, full,
-                                    hipMemcpyDeviceToHost, c->stream));
-        if (full != n)
-            RT_HIP(hipMemcpyAsync(dst + (size_t)(T - 1u) * tile, g + (size_t)q * msg + (size_t)(n - 1u) * tile, (size_t)last_rows * c->W * 4u,
-                                  hipMemcpyDeviceToHost, c->stream));
-    }
+    RT_HIP(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
     return RT_OK;
 }

@@ -79,11 +79,15 @@ __device__ inline void cube_fold(int face, int i, int j, int n, int& nf, int& ni
     nj = (T2 + m) >> 1;
 }
 
+// INDEXED (here and below): `A` is an object in memory -- the kernarg segment, read through a pointer (rt_triangles.hip:
+// reread_first_kernarg) --, and a lane's face record is LOADED from it by index, instead of being selected among the six
+// pointers and twelve sizes held in scalar registers: thirty SGPRs that the caller then does not need.
+template <bool INDEXED = false>
 __device__ __forceinline__ v3 cube_texel_at(const RtFrameArgs& A, int face, int n, int x, int y, const float* lut) {
-    const uint8_t* f = A.face[0];
+    const uint8_t* f = INDEXED ? A.face[face] : A.face[0];
 #pragma unroll
     for (int i = 1; i < 6; ++i)
-        if (face == i) f = A.face[i];
+        if (!INDEXED && face == i) f = A.face[i];
     const uchar4 p = *reinterpret_cast<const uchar4*>(f + 4u * ((size_t)y * (size_t)n + (size_t)x));
     if (lut) return V(lut[p.x], lut[p.y], lut[p.z]);
     return V((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f);
@@ -92,21 +96,22 @@ __device__ __forceinline__ v3 cube_texel_at(const RtFrameArgs& A, int face, int 
 // One bilinear tap.  Beyond a corner no face holds the texel: a + ((b - a) + (c - a)) / 3 with a = this
 // face's corner texel and b / c the corner texels of the faces across the u / v edge (Vulkan "Cube Map
 // Corner Handling": the mean of the three, and exactly their value when they agree).
+template <bool INDEXED = false>
 __device__ inline v3 cube_tap(const RtFrameArgs& A, int face, int n, int i, int j, const float* lut) {
     const bool oi = i < 0 || i >= n, oj = j < 0 || j >= n;
-    if (!oi && !oj) return cube_texel_at(A, face, n, i, j, lut);
+    if (!oi && !oj) return cube_texel_at<INDEXED>(A, face, n, i, j, lut);
     const int ci = i < 0 ? 0 : (i >= n ? n - 1 : i), cj = j < 0 ? 0 : (j >= n ? n - 1 : j);
     int f2, i2, j2;
     if (oi && oj) {
-        const v3 a = cube_texel_at(A, face, n, ci, cj, lut);
+        const v3 a = cube_texel_at<INDEXED>(A, face, n, ci, cj, lut);
         cube_fold(face, i, cj, n, f2, i2, j2);
-        const v3 b = cube_texel_at(A, f2, n, i2, j2, lut);
+        const v3 b = cube_texel_at<INDEXED>(A, f2, n, i2, j2, lut);
         cube_fold(face, ci, j, n, f2, i2, j2);
-        const v3 c = cube_texel_at(A, f2, n, i2, j2, lut);
+        const v3 c = cube_texel_at<INDEXED>(A, f2, n, i2, j2, lut);
         return add(a, divs(add(sub(b, a), sub(c, a)), 3.0f));
     }
     cube_fold(face, i, j, n, f2, i2, j2);
-    return cube_texel_at(A, f2, n, i2, j2, lut);
+    return cube_texel_at<INDEXED>(A, f2, n, i2, j2, lut);
 }
 
 // A.sky_flat (host: every face is one texel and the six texels agree -- the constant sky of the
@@ -118,7 +123,7 @@ __device__ inline v3 cube_tap(const RtFrameArgs& A, int face, int n, int i, int 
 // SKY: 0 = both decided at run time (wave-uniform flags), 1 = the caller's kernel is compiled for a flat
 // sky only (the filtering code is not even instantiated: the hierarchy kernel runs at its VGPR cap and must
 // not pay for it in the BASELINE configs C1-C4), 2 = compiled for a textured sky only.
-template <int SKY = 0>
+template <int SKY = 0, bool INDEXED = false>
 __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = nullptr) {
     if (SKY == 1) {
         // Flat sky, compiled in: every face is the same single texel c, so the face does not matter, and the
@@ -148,10 +153,11 @@ __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = 
         ma = ax;
     }
     // per-lane face index: select pointer/size without a runtime-indexed register array
-    const uint8_t* f = A.face[0]; int w = (int)A.fw[0], h = (int)A.fh[0];
+    const uint8_t* f = INDEXED ? A.face[face] : A.face[0];
+    int w = (int)(INDEXED ? A.fw[face] : A.fw[0]), h = (int)(INDEXED ? A.fh[face] : A.fh[0]);
 #pragma unroll
     for (int i = 1; i < 6; ++i)
-        if (face == i) { f = A.face[i]; w = (int)A.fw[i]; h = (int)A.fh[i]; }
+        if (!INDEXED && face == i) { f = A.face[i]; w = (int)A.fw[i]; h = (int)A.fh[i]; }
     const float s = 0.5f * (sc / ma) + 0.5f;
     const float t = 0.5f * (tc / ma) + 0.5f;
     const float u = s * (float)w - 0.5f;
@@ -184,7 +190,7 @@ __device__ inline v3 cube_sample(const RtFrameArgs& A, v3 r, const float* lut = 
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {          // one copy of the tap code for both rows
             top = row;
-            const v3 a = cube_tap(A, face, w, x0, y0 + k, lut), b = cube_tap(A, face, w, x0 + 1, y0 + k, lut);
+            const v3 a = cube_tap<INDEXED>(A, face, w, x0, y0 + k, lut), b = cube_tap<INDEXED>(A, face, w, x0 + 1, y0 + k, lut);
             row = lerp3(a, b, wu);
         }
         return lerp3(top, row, wv);

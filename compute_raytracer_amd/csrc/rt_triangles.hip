@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
 #pragma unroll 1
     for (int k = missed ? 0 : 1; k < 2; ++k) {
         if (k == 1) dir = primary_dir(Ae, sce, x_e, y_e);
-        const v3 sky = scale(sce.minIntensity, cube_sample<FLAT ? 1 : 0>(Ae, dir));
+        const v3 sky = scale(sce.minIntensity, cube_sample<FLAT ? 1 : 0, true>(Ae, dir));
         if (k == 0) color = divs(add(scale(sum_e, color), scale(affect_e, sky)), affect_e + sum_e);   // RK:120, 125
         else fog = sky;
     }
@@ -455,6 +455,7 @@ hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int he
     if (getenv("RT355_TRI_SMALL")) small = t.tlas_small;
     if (const char* e = getenv("RT355_TRI_SMALL")) small = std::min(small, (uint32_t)atoi(e));
 #endif
+    g_rt_tri_form = (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16) ? (int)small : 0;
     if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 2u) launch_tri<uint16_t, 6, true, 1, true, true, 2>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 1u) launch_tri<uint16_t, 5, true, 1, true, true, 1>(a, t, heatmap, s);
 #ifdef RT_TRI_DEV_ENV

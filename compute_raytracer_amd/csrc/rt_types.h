@@ -90,6 +90,7 @@ struct RtLaunchCfg {
 
 // The kernel form the last rt_launch_* call on this thread chose (rt_kernel_id of include/rt355.h).
 extern thread_local int g_rt_kernel_id;
+extern thread_local int g_rt_tri_form;     // rt_triangles.hip: the stack form it launched (rt_stats.tri_form)
 
 // Per-frame instance data of a triangle scene, carried in the kernarg block of apply_instances (rt_assemble.hip).
 struct RtInstanceArgs {

@@ -104,6 +104,9 @@ typedef struct rt_stats {
                                      (frames on k distinct streams in flight)                 */
     uint32_t instance_uploads;    /* frames whose per-frame instance data (rt_write_blas / _blas_lookup /
                                      _nodes at offset 0) travelled with the frame, without a drain */
+    uint32_t tri_form;            /* triangle scenes: the stack form of the latest frame's kernel -- 0: twenty top-level slots,
+                                     1: four (a top-level tree of depth <= 4 within 16 nodes), five waves per SIMD, 2: three
+                                     (depth <= 3, 8 nodes, <= 4 instances), six waves per SIMD */
     uint32_t pair_rebuilds;       /* times the library rebuilt its relinked copy of the BLAS trees (a drain + an upload:
                                      a node write reached the trees, or a frame named a root the copy did not know) */
 } rt_stats;
@@ -279,20 +282,18 @@ int rt_comm_destroy(rt_ctx* ctx);      /* back to a single-GPU context (rank 0 o
 int rt_set_comm_timeout(rt_ctx* ctx, uint32_t ms);
 
 /* Collective; replaces RendererRaytracing.render()'s submit (RR:442-446, 465) for the whole group:
- * this rank's tiles are rendered and exchanged over RCCL on the same stream (the gathered tiles stay rank-major in the
- * library's gather buffer; rt_read_frame / rt_frame_pixels hand out the row-major W x H frame).  root >= 0: only that rank receives (grouped ncclSend / ncclRecv -- each
+ * this rank's tiles are rendered, exchanged over RCCL on the same stream and de-interleaved into the
+ * row-major W x H frame.  root >= 0: only that rank receives (grouped ncclSend / ncclRecv -- each
  * rank's tiles travel once, over its direct xGMI link to the root); root = -1: every rank receives
  * (ncclAllGather).  Returns after enqueueing; rt_wait completes it.  Frames enqueued back to back
  * overlap on the device as with rt_render (four streams / buffer sets).  Every rank of the group must
  * make the same sequence of rt_render_gather calls with the same root. */
 int rt_render_gather(rt_ctx* ctx, int root);
 
-/* The frame of the latest rt_render_gather on a rank that received it.  rt_read_frame: a copy to host memory (waits first;
- * cap >= W*H*4) -- the copy itself de-interleaves the gathered tiles, one 2-D copy per rank, no kernel.  rt_frame_pixels: the
- * device address of the row-major frame for a device consumer (waits for the frame, runs the de-interleave kernel -- once per
- * frame -- and returns when it is complete; valid until four more frames are enqueued / rt_resize / rt_destroy).  After
- * rt_resize or rt_set_partition both fail with RT_ERR_STATE until the next rt_render_gather; RT_ERR_STATE on a rank that did
- * not receive.  rt_read_pixels / rt_device_pixels
+/* The frame of the latest rt_render_gather on a rank that received it: device address (valid until
+ * four more frames are enqueued / rt_resize / rt_destroy; after rt_resize or rt_set_partition the call
+ * fails with RT_ERR_STATE until the next rt_render_gather), or a copy to host memory (waits first;
+ * cap >= W*H*4).  RT_ERR_STATE on a rank that did not receive.  rt_read_pixels / rt_device_pixels
  * keep returning this rank's own tiles. */
 int rt_frame_pixels(rt_ctx* ctx, void** out_ptr, size_t* out_bytes);
 int rt_read_frame(rt_ctx* ctx, uint8_t* dst, size_t cap);

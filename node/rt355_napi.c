@@ -432,6 +432,7 @@ static napi_value Stats(napi_env env, napi_callback_info info) {
     set_num(env, obj, "kernelId", st.kernel_id);
     set_num(env, obj, "gridShare", st.grid_share);
     set_num(env, obj, "instanceUploads", st.instance_uploads);
+    set_num(env, obj, "triForm", st.tri_form);
     set_num(env, obj, "pairRebuilds", st.pair_rebuilds);
     return obj;
 }

@@ -27,7 +27,7 @@ def run_node(script, *args, check=True):
 def test_addon_loads_and_exports():
     out = run_node("const rt=require('./node/rt355.node');console.log(JSON.stringify([Object.keys(rt).sort(),rt.abiVersion()]))")
     names, ver = json.loads(out.stdout)
-    assert ver == 3
+    assert ver == 4
     for n in ["create", "destroy", "resize", "writeParams", "writeSpheres", "writeCubemapFace", "selectKernel",
               "setMode", "setPartition", "render", "wait", "readPixels", "stats", "readFrame", "createGroup", "destroyGroup",
               "groupSize", "groupCtx", "groupRender", "groupWait", "commUniqueId", "commInit", "renderGather", "hostAlloc",

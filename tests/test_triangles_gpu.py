@@ -378,3 +378,89 @@ def test_an_instance_that_changes_its_mesh_rebuilds_the_relinked_copy(oracle, va
         assert r.stats()["pair_rebuilds"] == (2 if variant == 0 else 0)
     finally:
         r.close()
+
+
+def deepen_top_level(scene, levels):
+    """The frame's top-level tree under `levels` extra inner nodes: each new node has the old tree (one level down) as its first
+    child and a leaf far away from everything (instance 0 again: never entered) as its second.  Same picture, a deeper walk."""
+    t = np.asarray(scene.frame["tlas_nodes"], np.float32).reshape(-1, 8)
+    n_old, extra = t.shape[0], 2 * levels
+    assert n_old + extra <= scene.tlasNodesMax
+    out = np.zeros((n_old + extra, 8), np.float32)
+    for k in range(levels):                                  # node 0 and the chain nodes at 1, 3, 5, ...: children at (2k+1, 2k+2)
+        i = 0 if k == 0 else 2 * k - 1
+        out[i] = [-1e4, -1e4, -1e4, 2 * k + 1, 1e4, 1e4, 1e4, 0]
+        out[2 * k + 2] = [9e3, 9e3, 9e3, 0, 9.1e3, 9.1e3, 9.1e3, 1]      # the far leaf
+    base = 2 * levels - 1                                    # where the old root goes; the rest of the old tree behind the chain
+    remap = lambda i: base if i == 0 else extra + i
+    for i in range(n_old):
+        row = t[i].copy()
+        if row[7] == 0:
+            row[3] = remap(int(row[3]))                      # old children sit side by side at left, left + 1 (left >= 1)
+        out[remap(i)] = row
+    scene.frame["tlas_nodes"] = out
+
+
+def expected_form(scene, mat):
+    """rt_tlas_fit.h restated: the stack form the library must pick for the frame's top-level tree (tiny 2, small 1, neither 0)."""
+    nodes = tri_buffers(scene, mat)["nodes"]
+    n = len(nodes)
+    def u32f(f):
+        f = float(f)
+        return 0 if not f > 0.0 else (4294967295 if f >= 4294967040.0 else int(f))
+    def fits(max_depth, max_nodes):
+        todo = [(0, 0)]
+        while todo:
+            i, d = todo.pop()
+            i = min(i, n - 1)
+            if i >= max_nodes: return False
+            if u32f(nodes[i, 7]) != 0: continue
+            if d >= max_depth: return False
+            left = u32f(nodes[i, 3])
+            todo += [(left, d + 1), ((left + 1) & 0xFFFFFFFF, d + 1)]
+        return True
+    if len(scene.instances) <= 4 and fits(3, 8): return 2
+    return 1 if fits(4, 16) else 0
+
+
+@pytest.mark.parametrize("n_models,deepen", [(1, 0), (3, 0), (3, 2), (4, 2), (11, 0), (11, 3)])
+def test_every_stack_form_of_the_kernel(oracle, n_models, deepen):
+    """The host walks every frame's top-level tree (rt_tlas_fit.h) and picks the kernel's stack form (rt_stats.tri_form): up to 4
+    instances in a tree of depth <= 3 -- three TLAS slots, six waves per SIMD for frames in flight, five (the four-slot form) for
+    awaited ones --, a tree of depth <= 4 within 16 nodes -- four slots, five waves --, anything else the reference's twenty.
+    n_models + the floor instances, some under extra levels; each awaited and in flight, under a textured sky, against the oracle."""
+    scene, mat = triangle_scene(seed=40 + n_models, n_models=n_models, rings=5, sectors=7)
+    sky = random_sky(n_models)
+    W, H, B = 200, 120, 3
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+    seen = set()
+    def advance():
+        scene.update(0.3)
+        levels = min(deepen, (scene.tlasNodesMax - len(scene.frame["tlas_nodes"])) // 2)
+        if levels:
+            deepen_top_level(scene, levels)
+    try:
+        for frame in range(2):
+            advance()
+            r.render()
+            ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
+            assert np.array_equal(r.read_pixels(), ref), (frame, diff_stats(r.read_pixels(), ref))
+            assert r.stats()["rays"] == rays
+            assert r.stats()["tri_form"] == min(expected_form(scene, mat), 1)        # awaited: never the six-wave form
+            seen.add(r.stats()["tri_form"])
+        for batch in range(2):                    # the second batch: the library has seen frames in flight (pipelined_hint)
+            host, want = r.host_frames(4), []
+            for f in range(4):
+                advance()
+                r.recalculateScene(); r.enqueue()
+                r.read_pixels_async(0, host[f])
+                want.append(oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)[0])
+            r.wait(); r.read_pixels_wait()
+            for f in range(4):
+                assert np.array_equal(host[f].reshape(H, W, 4), want[f]), (batch, f)
+        assert r.stats()["tri_form"] == expected_form(scene, mat)
+        seen.add(r.stats()["tri_form"])
+        if (n_models, deepen) == (1, 0): assert seen == {1, 2}
+        if (n_models, deepen) == (11, 3): assert 0 in seen
+    finally:
+        r.close()

@@ -11,7 +11,7 @@ KEY=${1:-C3-fast-v0-n1}; shift || true
 OUT=gpurun_out/$RD/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 12 --warmup 3 --no-cpu-baseline --serial-steps 0 $@"
+ARGS="--steps 12 --warmup 3 --no-cpu-baseline --serial-steps 0 --repeats 1 --no-node $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -o t -- python3 bench.py $ARGS > $OUT/${KEY}__pipelined_bench.json 2> $OUT/trace_pipelined.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -o t -- python3 bench.py $ARGS --serial > $OUT/${KEY}__serial_bench.json 2> $OUT/trace_serial.err
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o sq -- python3 bench.py $ARGS --serial > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err

@@ -38,11 +38,17 @@ copy_stream = torch.cuda.Stream()
 tile_bytes = 8 * W * 4
 T = (H + 7) // 8
 
+VP = ctypes.c_void_p
+def render_to(k, s):          # the C ABI directly: the Python renderer's render_to re-packs the scene parameters per call, 0.1 ms of host time
+    abi.check(L.rt_render_to(r._ctx, VP(gather[k].data_ptr()), msg, VP(s)), r._ctx)
+def assemble(k, s):
+    abi.check(L.rt_assemble_frame(r._ctx, VP(gather[k].data_ptr()), VP(frame[k].data_ptr()), world, VP(s)), r._ctx)
+
 def frame_of(k, mode):
     s = streams[k].cuda_stream
-    r.render_to(gather[k].data_ptr(), msg, s)
+    render_to(k, s)
     if mode == "assemble":
-        r.assemble_frame(gather[k].data_ptr(), frame[k].data_ptr(), world, s)
+        assemble(k, s)
     elif mode == "copy2d":
         # rt_read_frame's copies, here enqueued behind the frame on its own stream (a host that reads every frame)
         for q in range(world):
@@ -54,7 +60,7 @@ def frame_of(k, mode):
                                           ctypes.c_size_t(tile_bytes), ctypes.c_size_t(full), 2, ctypes.c_void_p(s))
                 assert rc == 0, rc
     elif mode == "assemble+copy":
-        r.assemble_frame(gather[k].data_ptr(), frame[k].data_ptr(), world, s)
+        assemble(k, s)
         rc = hip.hipMemcpyAsync(ctypes.c_void_p(host[k].data_ptr()), ctypes.c_void_p(frame[k].data_ptr()), ctypes.c_size_t(H * W * 4), 2, ctypes.c_void_p(s))
         assert rc == 0, rc
 
