@@ -161,10 +161,18 @@ def cpu_baseline_tri(cfg, scene, mat, sky, target_s, gpu_frame):
     }
 
 
+def a_no_children():
+    return os.environ.get("RT355_BENCH_NO_CHILDREN") == "1"
+
+
 def gpu_clocks():
     """The clock state of the GPU the line was measured on, asked of amd-smi (rocm-smi if that fails) in a child
     process: current / maximum shader and memory clocks and the performance level, whatever the tool reports of them."""
     import subprocess
+    # under rocprofv3 the profiler's preloaded library initialises the GPU in every process it is loaded into, and the tools are
+    # scripts that exec their interpreter: that exec is refused on this pool -- no clocks in a profiled run
+    if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")) or a_no_children():
+        return None
     for cmd in (["amd-smi", "metric", "--clock", "--json"], ["rocm-smi", "--showclocks", "--showperflevel", "--json"]):
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=30)
@@ -709,7 +717,7 @@ def main():
             out["cpu_baseline"] = cpu
         out["clocks"] = gpu_clocks()
         # the drop-in in the reference's host language, same workload (C3 and the reference's own scene)
-        if not multi and not a.no_node and a.mode == "fast" and a.variant == 0 and name in ("C3", "REF"):
+        if not multi and not a.no_node and not a_no_children() and a.mode == "fast" and a.variant == 0 and name in ("C3", "REF"):
             nb = node_bench(name, scene, mat, sky, cfg, min(a.steps, 100))
             out["node"] = nb
             out["node_loop_ms_per_step"] = nb.get("awaitedMsPerFrame")            # `await renderer.render()` per frame (src/app.ts:124-127)

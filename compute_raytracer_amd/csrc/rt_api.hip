@@ -919,7 +919,15 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         ts.n_blas_lookup = c->inst.lookup_on ? (uint32_t)c->inst.lookup.size() : (uint32_t)(c->d_blas_lookup[v].used / 4u);
         ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
         ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
-        ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u; ts.prio = 0u; ts.in_flight = hint ? 1u : 0u;
+        ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u; ts.prio = 0u; ts.in_flight = hint ? 1u : 0u; ts.dbg = nullptr;
+#ifdef RT355_DEV_EXPORTS
+        if (getenv("RT355_TRI_TIMELINE")) {
+            const size_t words = 3u * ((size_t)order_n + 3u * 1024u + 15u * 256u + 64u + 8u * ((c->W + 7u) / 8u));
+            if (c->d_tri_dbg.cap < words * 8u) { (void)hipFree(c->d_tri_dbg.p); c->d_tri_dbg.p = nullptr; RT_HIP(hipMalloc(&c->d_tri_dbg.p, words * 8u)); c->d_tri_dbg.cap = words * 8u; }
+            RT_HIP(hipMemsetAsync(c->d_tri_dbg.p, 0, c->d_tri_dbg.cap, s));
+            ts.dbg = static_cast<unsigned long long*>(c->d_tri_dbg.p);
+        }
+#endif
         // the top-level tree this frame walks (the mirror holds every node write, per-frame heads included): small enough for the
         // four-slot TLAS stack?  (rt_tlas_fit.h; the same constants as the kernel's: rt_tri_device.h kSmallStack / kSmallNodes)
         ts.tlas_small = 0u;
@@ -973,6 +981,14 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
 }
 
 #ifdef RT355_DEV_EXPORTS
+// development builds only (tools/tri_timeline.py): {start, end, tile << 8 | part} of every workgroup of the last triangle frame
+__attribute__((visibility("default"))) long long rt_debug_tri_timeline(rt_ctx* c, unsigned long long* dst, size_t cap_words) {
+    if (!c || !c->d_tri_dbg.p) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const size_t n = std::min(cap_words, c->d_tri_dbg.cap / 8u);
+    if (hipMemcpy(dst, c->d_tri_dbg.p, n * 8u, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long long)n;
+}
 // development builds only (tools/tile_cost_probe.py): the per-tile times of the last frame rendered on stream `set`
 __attribute__((visibility("default"))) int rt_debug_tile_cost(rt_ctx* c, int set, uint32_t* dst, uint32_t cap) {
     if (!c || set < 0 || set >= kStreams || !c->d_tile_cost[set].p) return -1;

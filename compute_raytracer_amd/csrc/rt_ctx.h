@@ -134,6 +134,7 @@ struct rt_ctx {
     RtFlow flow;
     bool flow_dirty = true;
     DevBuf d_flow;                               // the pair records
+    DevBuf d_tri_dbg;                            // development builds: the triangle kernel's per-workgroup timeline
     uint32_t n_cus = 256;
     uint32_t tex_w = 0, tex_h = 0;
     int scene_kind = 0;                    // 0 spheres, 1 triangles: the primitive type written last

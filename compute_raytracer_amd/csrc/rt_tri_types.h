@@ -26,6 +26,7 @@ struct RtTriScene {
     const uint32_t* tile_order;
     uint32_t* tile_cost;
     uint32_t in_flight;        // the caller keeps frames in flight (rt_api.hip: pipelined_hint): throughput over latency
+    unsigned long long* dbg;   // development builds (tools/tri_timeline.py): per workgroup {start, end (100 MHz ticks), tile << 8 | part}; null: off
     uint32_t prio;             // development builds: wave priority of the head of the work list (rt_triangles.hip)
     uint32_t xcd_rows;         // set by the launch (no work list): workgroup b renders row (b % 8) + 8 (b / 8 / tiles per row) -- a row per XCD
 };

@@ -231,6 +231,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     // different selections (the reference's scene one frame at a time: 0.43 and 0.49 ms alternating with the streams); the plain
     // maximum made it look short, and every list alternated between splitting a tile and not (0.45 / 0.55).  With the factors:
     // 0.385-0.395 ms, every frame, every stream (profiles/r04/tri_cost_series.log).
+#ifdef RT_TRI_DEV_ENV
+    if (T.dbg && threadIdx.x == 0u) {
+        T.dbg[3u * blockIdx.x] = clk0; T.dbg[3u * blockIdx.x + 1u] = wall_clock64(); T.dbg[3u * blockIdx.x + 2u] = ((unsigned long long)tile << 8) | part;
+    }
+#endif
     if (T.tile_cost && threadIdx.x == 0u) {
         const uint32_t dt = (uint32_t)(wall_clock64() - clk0);
         atomicMax(&T.tile_cost[tile], part >= 16u ? 3u * dt : (part < 4u ? dt + (dt >> 1) : dt));

@@ -1,7 +1,7 @@
-"""Host side of the persistent triangle kernel (rt_flow.hip), checked without a GPU: the relinked copy of the BLAS trees
+"""Host side of the triangle kernel's PAIRS forms, checked without a GPU (the library loads and rt_build_flow runs without a device): the relinked copy of the BLAS trees
 (compute_raytracer_amd/csrc/rt_flow_build.h through rt_build_flow of the C ABI).  A walk over the pair records must
 visit the reference's boxes in the reference's order -- here a restatement of the kernel's three walk steps in numpy
-float32 (same expressions, same order as rt_flow.hip / RK:168-341) runs over the records and is compared, hit for hit,
+float32 (same expressions, same order as rt_tri_device.h / RK:168-341) runs over the records and is compared, hit for hit,
 with the oracle's walk over the reference's node buffer, on the reference's own scene and on procedural ones."""
 import ctypes
 

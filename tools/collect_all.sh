@@ -1,11 +1,13 @@
 #!/bin/bash
 # Everything bench.py's roofline refers to, for every benched configuration, in one call on the GPU box:
-#   tools/collect_all.sh <round, e.g. r03>
+#   tools/collect_all.sh <round, e.g. r03> [configs, default "C3 C5 REF TRI TRI4K": a call on the GPU box is limited to 20 minutes, two calls fit]
 # kernel-trace stats (pipelined / serial), PMC passes (SQ, SQ in flight, FETCH_SIZE, WRITE_SIZE; LDS + stall passes for the
 # sphere configs, TCP / TCC / stall passes for the triangle configs), the counting builds' totals (C3, C5).
 # Then, in the build container:  cp -r gpurun_out/<round>/collected/* profiles/<round>/ && python tools/pmc_summary.py
 set -e
 RD=${1:-r03}
+WHAT=${2:-C3 C5 REF TRI TRI4K}
+want() { case " $WHAT " in *" $1 "*) return 0;; esac; return 1; }
 mkdir -p gpurun_out/$RD/collected/pmc
 run() {   # key, env assignment, bench args ...
   local key=$1 envs=$2; shift 2
@@ -15,12 +17,12 @@ run() {   # key, env assignment, bench args ...
   cp gpurun_out/$RD/prof/collected/*.json gpurun_out/$RD/prof/collected/*.csv gpurun_out/$RD/collected/
   echo "collected $key"
 }
-run C3-fast-v0-n1 RT_EXTRA_PASSES=1
-run C5-fast-v0-n1 RT_EXTRA_PASSES=1 --config C5 --steps 6 --warmup 2
-run REF-fast-v0-n1 RT_CACHE_PASSES=1 --config REF
-run TRI-fast-v0-n1 RT_CACHE_PASSES=1 --config TRI
-run TRI4K-fast-v0-n1 RT_CACHE_PASSES=1 --config TRI4K
-python3 tools/collect_counts.py C3 gpurun_out/$RD/collected
-python3 tools/collect_counts.py C5 gpurun_out/$RD/collected
+want C3 && run C3-fast-v0-n1 RT_EXTRA_PASSES=1
+want C5 && run C5-fast-v0-n1 RT_EXTRA_PASSES=1 --config C5 --steps 6 --warmup 2
+want REF && run REF-fast-v0-n1 RT_CACHE_PASSES=1 --config REF
+want TRI && run TRI-fast-v0-n1 RT_CACHE_PASSES=1 --config TRI
+want TRI4K && run TRI4K-fast-v0-n1 RT_CACHE_PASSES=1 --config TRI4K
+want C3 && python3 tools/collect_counts.py C3 gpurun_out/$RD/collected
+want C5 && python3 tools/collect_counts.py C5 gpurun_out/$RD/collected
 rm -rf gpurun_out/$RD/prof
 ls gpurun_out/$RD/collected gpurun_out/$RD/collected/pmc | head -80
