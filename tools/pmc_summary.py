@@ -65,8 +65,8 @@ def short(name):
     return re.sub(r"\(.*", "", re.sub(r"^void\s+", "", name)).replace("rtk::", "")
 
 
-RAY_TRACE = re.compile(r"bvh_pixels|trace_pixels|trace_paths|first_bounce|trace_triangles|heatmap_triangles|trace_flow|trace_tiles")
-GATHER = re.compile(r"trace_triangles|heatmap_triangles|trace_flow|trace_tiles|sky_resolve")      # reads are gathers: FETCH_SIZE x 1 (see above;
+RAY_TRACE = re.compile(r"bvh_pixels|trace_pixels|trace_paths|first_bounce|trace_triangles|heatmap_triangles")
+GATHER = re.compile(r"trace_triangles|heatmap_triangles|sky_resolve")      # reads are gathers: FETCH_SIZE x 1 (see above;
 # sky_resolve reads 16 bytes per lane at a 32-byte stride plus texel gathers: its raw FETCH_SIZE, 1.044 GB per C5 frame, is the size of its records, 1.062 GB)
 
 
@@ -96,9 +96,14 @@ def summarise(files):
             ex["valu_insts_per_simd_cycle"] = ex["valu_wave_insts_per_launch"] / (SIMDS * ex["shader_cycles_per_launch"])
             ex["valu_issue_frac"] = CYCLES_PER_VALU * ex["valu_insts_per_simd_cycle"]
             ex["sustained_clock_ghz"] = ex["shader_cycles_per_launch"] / ex["kernel_ns"]
-        fl = passes.get("sqflight", {}).get(dom)
-        if fl and "SQ_INSTS_VALU" in fl:        # the launches of frames in flight (collect_profiles.sh)
-            ex["valu_wave_insts_per_launch_in_flight"] = fl["SQ_INSTS_VALU"]
+        # the launches of frames in flight (collect_profiles.sh): THAT pass's dominant ray-trace kernel -- the triangle path runs
+        # another instantiation for frames in flight (six waves per SIMD) than for awaited ones (five)
+        flp = {k: v for k, v in passes.get("sqflight", {}).items() if RAY_TRACE.search(k) and "SQ_INSTS_VALU" in v}
+        if flp:
+            domf = max(flp, key=lambda k: flp[k]["total_ns"])
+            ex["valu_wave_insts_per_launch_in_flight"] = flp[domf]["SQ_INSTS_VALU"]
+            if domf != dom:
+                entry["kernel_in_flight"] = short(domf)
         entry["executed"] = ex
     # memory side (collect_profiles.sh RT_CACHE_PASSES): L1 -> L2 read requests (64 B each), their mean latency in
     # shader cycles, cycles the L1 stalled on pending misses, L2 hit rate
