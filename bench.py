@@ -302,6 +302,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RT355_BENCH_ONE_DEVICE") == "1":     # testing aid: every rank on device 0 (a one-GPU box rehearsing N > 1, if RCCL permits it)
+        local_rank = 0
     if world != a.gpus:
         a.gpus = world                    # a launcher's WORLD_SIZE is what there is
 

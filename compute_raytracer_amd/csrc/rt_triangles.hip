@@ -269,7 +269,7 @@ __device__ __forceinline__ uint32_t cost_class(uint32_t c) {     // quarter-octa
     return 4u * e + ((c >> (e - 2u)) & 3u) - 4u;
 }
 __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __restrict__ cost, uint32_t* __restrict__ scan, uint32_t* __restrict__ order,
-                                                          uint32_t n, uint32_t wave_slots, uint32_t mult16, uint32_t cap16) {
+                                                          uint32_t n, uint32_t wave_slots, uint32_t mult16, uint32_t cap16, uint32_t mult4) {
     __shared__ uint32_t bin[128];
     __shared__ unsigned long long total;
     __shared__ uint32_t last;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __rest
     if (threadIdx.x == 0u) {                       // exclusive prefix over the classes, longest class first
         const unsigned long long thr = total / (2ull * (wave_slots ? wave_slots : 1u));
         auto cls_of = [&](unsigned long long v) { return cost_class(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v); };
-        const uint32_t kt = cls_of(thr);
+        const uint32_t kt = cls_of((unsigned long long)mult4 * thr);           // mult4 / 2 times the throughput time: as quarters
         const uint32_t kw = cls_of(4ull * thr);           // twice the throughput time
         const uint32_t k16 = cls_of((unsigned long long)mult16 * thr);          // mult16 / 2 times the throughput time: as sixteenths
         uint32_t acc = 0u, split = 0u, split16 = 0u;
@@ -431,14 +431,15 @@ hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* scan, uint32_t* order
     // Sixteenths from twice the throughput time on, at most 64 tiles (1 / 2 / 4 / 8 times: REF 0.459 / 0.449 / 0.537 / 0.539 ms one at a
     // time, TRI 0.255 / 0.256 / 0.291 / 0.372; 64 against 256 tiles: REF 0.449 against 0.465; a third level of single pixels
     // changes nothing: profiles/r04/tri_split_sweep16.log, tri_split_sweep64.log).  launch_tri sizes the grid for 256.
-    uint32_t mult16 = 4u, cap16 = 64u;
+    uint32_t mult16 = 4u, cap16 = 64u, mult4 = 1u;
 #ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_MULT4")) mult4 = (uint32_t)atoi(e);
     if (const char* e = getenv("RT355_TRI_MULT16")) mult16 = (uint32_t)atoi(e);
     if (const char* e = getenv("RT355_TRI_CAP16")) cap16 = std::min(256u, (uint32_t)atoi(e));
     if (const char* e = getenv("RT355_TRI_SLOTS")) wave_slots = (uint32_t)atoi(e);
 #endif
     const uint32_t per = rtk::kOrderBlock * rtk::kOrderPerThread, blocks = (n_tiles + per - 1u) / per;
-    hipLaunchKernelGGL(rtk::order_hist, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles, wave_slots, mult16, cap16);
+    hipLaunchKernelGGL(rtk::order_hist, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles, wave_slots, mult16, cap16, mult4);
     hipLaunchKernelGGL(rtk::order_scatter, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles);
     return hipGetLastError();
 }
