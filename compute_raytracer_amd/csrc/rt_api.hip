@@ -852,14 +852,63 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     cfg.mode = filter_ok ? c->mode : (int)RT_MODE_STRICT;
     cfg.variant = (c->variant == 4 || c->variant == 5) ? 0 : c->variant;   // rt_kernels.hip numbers its default 0
 
+    const uint32_t v = slot % (uint32_t)kVersions;
+    RtTriScene ts;
+    std::memset(&ts, 0, sizeof ts);
+    if (tri) {
+        ts.nodes = static_cast<const float4*>(c->d_nodes[v].p);
+        ts.blas = static_cast<const float*>(c->d_blas[v].p);
+        ts.tri = static_cast<const float*>(c->d_tri.p);
+        ts.corners = static_cast<const float4*>(c->d_corners.p);
+        ts.tri_lookup = static_cast<const float*>(c->d_tri_lookup.p);
+        ts.blas_lookup = static_cast<const float*>(c->d_blas_lookup[v].p);
+        ts.tex = static_cast<const uint8_t*>(c->d_tex.p);
+        ts.n_nodes = (uint32_t)(c->nodes_used / 32u);
+        ts.n_blas = c->inst.blas_on ? (uint32_t)(c->inst.blas.size() / 20u) : (uint32_t)(c->d_blas[v].used / 80u);
+        ts.n_tri = (uint32_t)(c->d_tri.used / 160u);
+        ts.n_tri_lookup = (uint32_t)(c->d_tri_lookup.used / 4u);
+        ts.n_blas_lookup = c->inst.lookup_on ? (uint32_t)c->inst.lookup.size() : (uint32_t)(c->d_blas_lookup[v].used / 4u);
+        ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
+        ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
+        ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u; ts.prio = 0u; ts.in_flight = hint ? 1u : 0u; ts.dbg = nullptr;
+        // the top-level tree this frame walks (the mirror holds every node write, per-frame heads included): small enough for the
+        // four-slot TLAS stack?  (rt_tlas_fit.h; the same constants as the kernel's: rt_tri_device.h kSmallStack / kSmallNodes)
+        ts.tlas_small = 0u;
+        if (c->h_nodes.size() / 8u >= ts.n_nodes) {
+            if (ts.n_blas <= 4u && rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 3u, 8u)) ts.tlas_small = 2u;
+            else if (rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 4u, 16u)) ts.tlas_small = 1u;
+        }
+        // two-byte stack entries (count << 14 | x): every meta of the records and of this frame's roots must fit them
+        ts.p16_ok = (have_pairs && c->flow.max_count <= 3u && c->flow.max_x <= 16383u) ? 1u : 0u;
+        for (uint32_t i = 0; i < 12u && ts.p16_ok; ++i)
+            if ((root_meta[i] >> 16) > 3u || (root_meta[i] & 0xFFFFu) > 16383u) ts.p16_ok = 0u;
+        ts.pairs = (have_pairs && ts.n_blas <= 12u) ? static_cast<const float4*>(c->d_flow.p) : nullptr;
+        for (uint32_t i = 0; i < 12u; ++i) ts.root_meta[i] = root_meta[i];
+        // which form of the kernel renders the frame (rt_triangles.hip); the small forms take the frame's instance data in their
+        // own arguments, in the layout they stage it in
+        ts.form = (uint32_t)rt_tri_stack_form(ts, c->kernel == RT_KERNEL_HEATMAP);
+        if (ts.form != 0u) {
+            const uint32_t nn = std::min(ts.n_nodes, kInstHeadNodes), nb = std::min(ts.n_blas, kInstBlas);
+            std::memcpy(ts.inst.head, c->h_nodes.data(), (size_t)nn * 32u);
+            std::memcpy(ts.inst.blas, c->inst.blas.data(), (size_t)nb * 80u);
+            const uint32_t nl = std::min(ts.n_blas_lookup, nb);
+            for (uint32_t k = 0; k < nb; ++k) {
+                if (k < nl) ts.inst.blas[20u * k + 19u] = c->inst.lookup[k];
+                std::memcpy(&ts.inst.blas[20u * k + 17u], &root_meta[k], 4);
+            }
+            if (c->inst_gen_carried != c->inst.gen) { c->inst_gen_carried = c->inst.gen; ++c->stats.instance_uploads; }
+        }
+    }
     // Per-frame instance data (RR:169-192) travels with the frame: version `v` of the three buffers is brought to the
     // host's current state by a one-workgroup kernel whose kernarg block holds the values, in front of the ray-trace
     // kernel on the frame's stream.  The frame kVersions slots back read the same version: it must be through.
     // Ordering does not lean on which stream a slot happens to use (a host may rotate rt_render_to over any number of its own
     // streams): before a version is rewritten, EVERY frame in flight that reads it must be through; and a frame that reads a
     // version another stream brought up to date waits for that update.
-    const uint32_t v = slot % (uint32_t)kVersions;
-    if (tri && c->ver_gen[v] != c->inst.gen) {
+    // (The small forms of the triangle kernel -- the reference's scene, any scene of a few instances -- read none of the three
+    // buffers: their instance data is in the kernel's own arguments, ts.inst above.  No kernel, no event, no wait; the versions
+    // simply fall behind, and a later frame of another form brings its own up to date.)
+    if (tri && ts.form == 0u && c->ver_gen[v] != c->inst.gen) {
         for (uint32_t i = v; i < slot; i += (uint32_t)kVersions) RT_HIP(hipStreamWaitEvent(s, c->ev_k1[i], 0));
         RtInstanceArgs ia;
         ia.nodes = static_cast<float*>(c->d_nodes[v].p);
@@ -877,7 +926,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         c->ver_stream[v] = s;
         c->ver_gen[v] = c->inst.gen;
         ++c->stats.instance_uploads;
-    } else if (tri && c->ev_ver[v] && c->ver_stream[v] != s) {
+    } else if (tri && ts.form == 0u && c->ev_ver[v] && c->ver_stream[v] != s) {
         RT_HIP(hipStreamWaitEvent(s, c->ev_ver[v], 0));
     }
     // tile order of the triangle kernel: only for frames on the library's own streams (each has its set of buffers)
@@ -904,22 +953,6 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     RT_HIP(hipEventRecord(c->ev_k0[slot], s));
     g_rt_kernel_id = RT_KID_NONE;
     if (tri) {
-        RtTriScene ts;
-        ts.nodes = static_cast<const float4*>(c->d_nodes[v].p);
-        ts.blas = static_cast<const float*>(c->d_blas[v].p);
-        ts.tri = static_cast<const float*>(c->d_tri.p);
-        ts.corners = static_cast<const float4*>(c->d_corners.p);
-        ts.tri_lookup = static_cast<const float*>(c->d_tri_lookup.p);
-        ts.blas_lookup = static_cast<const float*>(c->d_blas_lookup[v].p);
-        ts.tex = static_cast<const uint8_t*>(c->d_tex.p);
-        ts.n_nodes = (uint32_t)(c->nodes_used / 32u);
-        ts.n_blas = c->inst.blas_on ? (uint32_t)(c->inst.blas.size() / 20u) : (uint32_t)(c->d_blas[v].used / 80u);
-        ts.n_tri = (uint32_t)(c->d_tri.used / 160u);
-        ts.n_tri_lookup = (uint32_t)(c->d_tri_lookup.used / 4u);
-        ts.n_blas_lookup = c->inst.lookup_on ? (uint32_t)c->inst.lookup.size() : (uint32_t)(c->d_blas_lookup[v].used / 4u);
-        ts.tex_w = c->tex_w; ts.tex_h = c->tex_h;
-        ts.packed_ok = (c->node_count_max <= 65535u && ts.n_nodes <= 65536u && ts.n_tri_lookup <= 65536u) ? 1u : 0u;
-        ts.tile_order = nullptr; ts.tile_cost = nullptr; ts.xcd_rows = 0u; ts.prio = 0u; ts.in_flight = hint ? 1u : 0u; ts.dbg = nullptr;
 #ifdef RT355_DEV_EXPORTS
         if (getenv("RT355_TRI_TIMELINE")) {
             const size_t words = 3u * ((size_t)order_n + 3u * 1024u + 15u * 256u + 64u + 8u * ((c->W + 7u) / 8u));
@@ -928,19 +961,6 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             ts.dbg = static_cast<unsigned long long*>(c->d_tri_dbg.p);
         }
 #endif
-        // the top-level tree this frame walks (the mirror holds every node write, per-frame heads included): small enough for the
-        // four-slot TLAS stack?  (rt_tlas_fit.h; the same constants as the kernel's: rt_tri_device.h kSmallStack / kSmallNodes)
-        ts.tlas_small = 0u;
-        if (c->h_nodes.size() / 8u >= ts.n_nodes) {
-            if (ts.n_blas <= 4u && rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 3u, 8u)) ts.tlas_small = 2u;
-            else if (rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 4u, 16u)) ts.tlas_small = 1u;
-        }
-        // two-byte stack entries (count << 14 | x): every meta of the records and of this frame's roots must fit them
-        ts.p16_ok = (have_pairs && c->flow.max_count <= 3u && c->flow.max_x <= 16383u) ? 1u : 0u;
-        for (uint32_t i = 0; i < 12u && ts.p16_ok; ++i)
-            if ((root_meta[i] >> 16) > 3u || (root_meta[i] & 0xFFFFu) > 16383u) ts.p16_ok = 0u;
-        ts.pairs = (have_pairs && ts.n_blas <= 12u) ? static_cast<const float4*>(c->d_flow.p) : nullptr;
-        for (uint32_t i = 0; i < 12u; ++i) ts.root_meta[i] = root_meta[i];
 #ifdef RT355_DEV_EXPORTS
         if (order_set >= 0 && getenv("RT355_KEEP_TILE_COST")) RT_HIP(hipMemsetAsync(c->d_tile_cost[order_set].p, 0, (size_t)order_n * 4u, s));
 #endif
@@ -957,20 +977,26 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         else RT_HIP(rt_launch_trace(fa, cfg, s));
     }
     RT_HIP(hipEventRecord(c->ev_k1[slot], s));
-    // the frame's counters summed into host-visible memory and zeroed for the slot's next frame (rt_assemble.hip)
-    RT_HIP(rt_launch_frame_epilogue(counters, c->h_rays + 2u * slot, (uint32_t)(kCtrlBytes / 8u), s));
-    RT_HIP(hipEventRecord(c->ev_done[slot], s));
 #ifdef RT355_DEV_EXPORTS
     if (order_set >= 0 && getenv("RT355_KEEP_TILE_COST")) {      // tools/tile_cost_probe.py reads the times of whole tiles in index order
         c->order_tiles[order_set] = 0;
         order_set = -1;
     }
 #endif
+    // The end of the frame: its counters summed into host-visible memory and zeroed for the slot's next frame (rt_assemble.hip:
+    // frame_epilogue), then the event rt_wait waits for -- as early as can be: an awaited frame's successor is launched by a host
+    // that has to wake up first, and its turnaround (15-30 us) is what the work-list kernels behind the event hide in.  (Round 5
+    // ran the epilogue inside order_hist's first workgroup to save a link of the chain: the host woke 11 us later and the frame
+    // period GREW by as much -- TRI 0.276 -> 0.298 ms; profiles/r05/ref_awaited_trace.log.)
+    RT_HIP(rt_launch_frame_epilogue(counters, c->h_rays + 2u * slot, (uint32_t)(kCtrlBytes / 8u), s));
+    RT_HIP(hipEventRecord(c->ev_done[slot], s));
     if (order_set >= 0) {
         // after the frame's event: rt_wait does not wait for it, the stream's next frame does
-        RT_HIP(rt_launch_order_tiles(static_cast<uint32_t*>(c->d_tile_cost[order_set].p),
-                                     reinterpret_cast<uint32_t*>(static_cast<char*>(c->d_tile_cost[order_set].p) + c->d_tile_cost[order_set].cap),
-                                     static_cast<uint32_t*>(c->d_tile_order[order_set].p), order_n, c->wave_slots, s));
+        uint32_t* const cost = static_cast<uint32_t*>(c->d_tile_cost[order_set].p);
+        uint32_t* const scan = reinterpret_cast<uint32_t*>(static_cast<char*>(c->d_tile_cost[order_set].p) + c->d_tile_cost[order_set].cap);
+        uint32_t* const list = static_cast<uint32_t*>(c->d_tile_order[order_set].p);
+        RT_HIP(rt_launch_order_hist(cost, scan, list, order_n, c->wave_slots, nullptr, nullptr, 0u, s));
+        RT_HIP(rt_launch_order_scatter(cost, scan, list, order_n, s));
         c->order_tiles[order_set] = order_n;
     }
     c->stats.kernel_id = (uint32_t)g_rt_kernel_id;

@@ -50,24 +50,11 @@ hipError_t rt_launch_apply_instances(const RtInstanceArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// The end of a frame on its stream: its partial ray counters summed, the sum and the frame's fault word (rt_device.h:
-// report_fault) stored where the host reads them without a copy -- pinned, device-visible memory --, and the frame's
-// counter set and control block (queue counts, pixel cursor) zeroed for the next frame that takes this slot.  rt_wait then
-// needs ONE synchronisation, on the event behind this kernel: no read-back and memset of its own, whose launch and second
-// wait cost a caller that waits after every frame ~0.1 ms per frame (round 3).
+// The end of a frame on its stream (rt_types.h: rt_frame_epilogue_body).  rt_wait then needs ONE synchronisation, on the event
+// behind this kernel: no read-back and memset of its own, whose launch and second wait cost a caller that waits after every
+// frame ~0.1 ms per frame (round 3).
 __global__ __launch_bounds__(256) void frame_epilogue(unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host, uint32_t words) {
-    const uint32_t t = threadIdx.x;
-    unsigned long long v = t < RT_RAY_COUNTERS ? ctr[t * (RT_RAY_COUNTER_STRIDE / 8u)] : 0ull;
-    const unsigned long long fault = t == 0u ? ctr[1] : 0ull;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);      // RT_RAY_COUNTERS <= 64: all in the first wave
-    __syncthreads();                                                           // every read is done
-    for (uint32_t i = t; i < words; i += 256u) ctr[i] = 0ull;
-    if (t == 0u) {
-        host[0] = v;
-        host[1] = fault;
-        __threadfence_system();
-    }
+    rt_frame_epilogue_body(ctr, host, words);
 }
 
 hipError_t rt_launch_frame_epilogue(unsigned long long* counters, unsigned long long* host, uint32_t words, hipStream_t s) {

@@ -122,6 +122,7 @@ struct rt_ctx {
         bool blas_on = false, lookup_on = false; // the last write of that buffer was a per-frame (small) one
         uint64_t gen = 0;                        // bumped by every per-frame write
     } inst;
+    uint64_t inst_gen_carried = 0;               // inst.gen the last frame of a small form took along in its arguments (rt_stats.instance_uploads)
     uint64_t ver_gen[kVersions] = {0, 0, 0, 0};  // inst.gen each device version holds
     hipEvent_t ev_ver[kVersions] = {nullptr};    // behind the apply_instances kernel that last brought the version up to date ...
     hipStream_t ver_stream[kVersions] = {nullptr};   // ... on this stream

@@ -49,11 +49,23 @@ __device__ __forceinline__ NodeR load_node_head(const RtTriScene& T, const TriLd
     n.hi = V(b.x, b.y, b.z); n.count = b.w;
     return n;
 }
-template <int WAVES, uint32_t NODES = kLdsNodes, uint32_t BLAS = kLdsBlas>
+template <int WAVES, uint32_t NODES = kLdsNodes, uint32_t BLAS = kLdsBlas, bool INST = false>
 __device__ __forceinline__ TriLds stage_head(const RtTriScene& T, float4* s_nodes, float* s_blas) {
     TriLds L;
     L.n_nodes = T.n_nodes < NODES ? T.n_nodes : NODES;
     L.n_blas = T.n_blas < BLAS ? T.n_blas : BLAS;
+    if constexpr (INST) {
+        // the frame's instance data came with the kernel's arguments, laid out as staged (rt_tri_types.h: RtTriInst; the host put
+        // the lookup entries and the roots' metas into the records' padding words)
+        static_assert(NODES <= kInstHeadNodes && BLAS <= kInstBlas, "RtTriInst holds what the small forms stage");
+        L.n_lookup = T.n_blas_lookup < L.n_blas ? T.n_blas_lookup : L.n_blas;
+        float* const sn = reinterpret_cast<float*>(s_nodes);
+        for (uint32_t i = threadIdx.x; i < 8u * L.n_nodes; i += 64 * WAVES) sn[i] = T.inst.head[i];
+        for (uint32_t i = threadIdx.x; i < 20u * L.n_blas; i += 64 * WAVES) s_blas[i] = T.inst.blas[i];
+        __syncthreads();
+        L.nodes = s_nodes; L.blas = s_blas;
+        return L;
+    }
     for (uint32_t i = threadIdx.x; i < 2u * L.n_nodes; i += 64 * WAVES) s_nodes[i] = T.nodes[i];
     // (the last padding word of staged record k carries entry k of the BLAS lookup table, RK:223: one dependent global load
     // less per instance and ray)
@@ -317,12 +329,12 @@ __device__ __forceinline__ TriHit trace_tlas(const RtTriScene& T, const TriLds& 
 // What hitTriangle (RK:381-387) and traceBLAS (RK:334-338) attach to the accepted hit -- in two parts, so that
 // only the normal (which the reflection needs) is carried across the shadow ray's traversal; texture
 // coordinate and colour are read when the bounce is shaded.
-__device__ __forceinline__ v3 hit_normal(const RtTriScene& T, const TriHit& h) {
+// m: the hit instance's record (inverseModel, column-major) -- T.blas + 20 h.blas, or the staged copy of it
+__device__ __forceinline__ v3 hit_normal(const RtTriScene& T, const TriHit& h, const float* m) {
     const float* tr = T.tri + 40u * (size_t)tri_of(T, h.tri);
     const float w = 1.0f - h.u - h.v;                                                // RK:381
     const v3 nA = V(tr[4], tr[5], tr[6]), nB = V(tr[16], tr[17], tr[18]), nC = V(tr[28], tr[29], tr[30]);
     const v3 n = add(add(scale(w, nA), scale(h.u, nB)), scale(h.v, nC));             // RK:382
-    const float* m = T.blas + 20u * (size_t)h.blas;
     const v3 tn = V(((m[0] * n.x + m[1] * n.y) + m[2] * n.z) + m[3] * 0.0f,
                     ((m[4] * n.x + m[5] * n.y) + m[6] * n.z) + m[7] * 0.0f,
                     ((m[8] * n.x + m[9] * n.y) + m[10] * n.z) + m[11] * 0.0f);       // RK:335-337

@@ -2,6 +2,16 @@
 #pragma once
 #include "rt_types.h"
 
+// The frame's instance data (RR:169-192: the head of the node buffer = the top-level tree, the BLAS records, the BLAS lookup) as the
+// SMALL forms of the triangle kernel take it: by value, in the kernel's own argument block -- what they stage in LDS, in the
+// layout they stage it in (word 19 of record k: entry k of the lookup table; word 17: the root's relinked meta).  A frame of these
+// forms reads nothing else of the per-frame buffers: no apply_instances kernel in front of it, no version of those buffers to wait for.
+constexpr uint32_t kInstHeadNodes = 16u, kInstBlas = 12u;       // = rt_tri_device.h kSmallNodes, kLdsBlas
+struct RtTriInst {
+    float head[8u * kInstHeadNodes];
+    float blas[20u * kInstBlas];
+};
+
 struct RtTriScene {
     const float4* nodes;       // [n_nodes][2]  {min.xyz, leftChildIndex}, {max.xyz, primitiveCount}
     const float* blas;         // [n_blas][20]  inverseModel (column-major), rootNodeIndex, pad
@@ -25,13 +35,20 @@ struct RtTriScene {
     uint32_t root_meta[12];    // instances the tile kernel stages (rt_tri_device.h: kLdsBlas)
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    uint32_t form;             // the stack form rt_tri_stack_form chose for this frame (0 / 1 / 2 = SMALL of rt_triangles.hip); forms 1 and 2 read `inst`
+    RtTriInst inst;
     uint32_t in_flight;        // the caller keeps frames in flight (rt_api.hip: pipelined_hint): throughput over latency
     unsigned long long* dbg;   // development builds (tools/tri_timeline.py): per workgroup {start, end (100 MHz ticks), tile << 8 | part}; null: off
     uint32_t prio;             // development builds: wave priority of the head of the work list (rt_triangles.hip)
     uint32_t xcd_rows;         // set by the launch (no work list): workgroup b renders row (b % 8) + 8 (b / 8 / tiles per row) -- a row per XCD
 };
 
+// Which stack form rt_launch_triangles runs the frame as: 0 twenty TLAS slots, 1 four (five waves per SIMD), 2 three (six waves).
+// The caller stores the answer in t.form before the launch and, for 1 and 2, fills t.inst.
+int rt_tri_stack_form(const RtTriScene& t, int heatmap);
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);
 uint32_t rt_order_scan_words(void);      // words of scan space rt_launch_order_tiles needs, zeroed once (it leaves them zero)
-hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s);
+hipError_t rt_launch_order_hist(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots,
+                                unsigned long long* counters, unsigned long long* host, uint32_t words, hipStream_t s);   // + the frame's epilogue
+hipError_t rt_launch_order_scatter(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, hipStream_t s);
 hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* lookup, uint32_t n_slots, uint32_t n_tri, hipStream_t s);

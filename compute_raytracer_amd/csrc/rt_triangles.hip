@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     __shared__ uint32_t s_rays[WAVES];             // traversals of this wave's lanes (the frame's ray counter, RK:114 + RK:153)
     if ((threadIdx.x & 63u) == 0u) s_rays[threadIdx.x >> 6] = 0u;
     Parked<PARK, stride> pk(s_park + threadIdx.x);
-    const TriLds L = stage_head<WAVES, NODES, BLAS>(T, s_nodes, s_blas);
+    const TriLds L = stage_head<WAVES, NODES, BLAS, (SMALL != 0)>(T, s_nodes, s_blas);
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // one workgroup per tile, or per quarter of a tile the previous frame on this stream found long (order_tiles)
@@ -159,7 +159,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
         }
         if (bounce == 0) pk.template put<3>(h.t);                                    // RK:116-118
         const float next = affect + sum;                                             // RK:120
-        const v3 normal = hit_normal(T, h);
+        // (SMALL: every instance record is staged, and the per-frame buffers are not this frame's: rt_tri_types.h RtTriInst)
+        const v3 normal = hit_normal(T, h, SMALL ? L.blas + 20u * (uint32_t)h.blas : T.blas + 20u * (size_t)h.blas);
         const Albedo s = hit_albedo(T, h.tri, h.u, h.v);
         ro = add(ro, scale(h.t, rd));                                                // RK:129
         rd = normalize(reflect(rd, normal));                                         // RK:130
@@ -268,11 +269,16 @@ __device__ __forceinline__ uint32_t cost_class(uint32_t c) {     // quarter-octa
     const uint32_t e = 31u - (uint32_t)__clz(c);
     return 4u * e + ((c >> (e - 2u)) & 3u) - 4u;
 }
+// ctr / host / words: optionally the frame's epilogue (rt_types.h: rt_frame_epilogue_body), run by the first workgroup; not used
+// by the product -- the host must hear of the frame's end before these kernels, not after (rt_api.hip: rt_enqueue).
 __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __restrict__ cost, uint32_t* __restrict__ scan, uint32_t* __restrict__ order,
-                                                          uint32_t n, uint32_t wave_slots, uint32_t mult16, uint32_t cap16, uint32_t mult4) {
-    __shared__ uint32_t bin[128];
+                                                          uint32_t n, uint32_t wave_slots, uint32_t mult16, uint32_t cap16, uint32_t mult4,
+                                                          unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host, uint32_t words) {
+    static_assert(kOrderBlock == 256u, "rt_frame_epilogue_body is written for 256 threads");
+    __shared__ uint32_t bin[128], start[128];
     __shared__ unsigned long long total;
     __shared__ uint32_t last;
+    if (blockIdx.x == 0u && ctr) rt_frame_epilogue_body(ctr, host, words);
     if (threadIdx.x < 128u) bin[threadIdx.x] = 0u;
     if (threadIdx.x == 0u) total = 0ull;
     __syncthreads();
@@ -292,22 +298,23 @@ __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __rest
     if (threadIdx.x < 128u) bin[threadIdx.x] = __hip_atomic_load(&scan[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0u) total = __hip_atomic_load(reinterpret_cast<unsigned long long*>(scan + 128), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (threadIdx.x == 0u) {                       // exclusive prefix over the classes, longest class first
+    // start[k] = tiles in the classes ABOVE k (the longer ones): class k's first position in the list -- every thread its own sum
+    if (threadIdx.x < 128u) {
+        uint32_t acc = 0u;
+        for (uint32_t k = threadIdx.x + 1u; k < 128u; ++k) acc += bin[k];
+        start[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
         const unsigned long long thr = total / (2ull * (wave_slots ? wave_slots : 1u));
         auto cls_of = [&](unsigned long long v) { return cost_class(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v); };
         const uint32_t kt = cls_of((unsigned long long)mult4 * thr);           // mult4 / 2 times the throughput time: as quarters
         const uint32_t kw = cls_of(4ull * thr);           // twice the throughput time
         const uint32_t k16 = cls_of((unsigned long long)mult16 * thr);          // mult16 / 2 times the throughput time: as sixteenths
-        uint32_t acc = 0u, split = 0u, split16 = 0u;
-        bool pays = false;                         // some tile takes more than twice the throughput time: the frame waits for it.
-        for (int k = 127; k >= 0; --k) {           // (Otherwise quarters only add waves: 4K, 0.77 -> 0.81 ms with them.)
-            const uint32_t v = bin[k];
-            bin[k] = acc; acc += v;
-            if (k > (int)kt) split = acc;          // tiles of the classes above the threshold's: all longer than it
-            if (k > (int)k16) split16 = acc;
-            if (k > (int)kw && v) pays = true;
-        }
-        if (!pays) split = split16 = 0u;
+        uint32_t split = start[kt], split16 = start[k16];      // tiles of the classes above the threshold's: all longer than it
+        // some tile takes more than twice the throughput time: the frame waits for it.  (Otherwise quarters only add waves: 4K,
+        // 0.77 -> 0.81 ms with them.)
+        if (start[kw] == 0u) split = split16 = 0u;
         const uint32_t most = n / 16u < 1024u ? n / 16u : 1024u, most16 = n / 64u < cap16 ? n / 64u : cap16;      // rt_tri_grid
         if (split16 > most16) split16 = most16;
         if (split > most) split = most;
@@ -315,8 +322,7 @@ __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __rest
         order[0] = split - split16;                // tiles rendered as four quarters ...
         order[1] = split16;                        // ... behind the tiles rendered as sixteen 2x2 blocks: the head of the list
     }
-    __syncthreads();
-    if (threadIdx.x < 128u) { scan[132u + threadIdx.x] = bin[threadIdx.x]; scan[threadIdx.x] = 0u; }   // first positions; bins zero for the next frame
+    if (threadIdx.x < 128u) { scan[132u + threadIdx.x] = start[threadIdx.x]; scan[threadIdx.x] = 0u; }   // first positions; bins zero for the next frame
     if (threadIdx.x < 4u) scan[128u + threadIdx.x] = 0u;                                                // total, ticket
 }
 __global__ __launch_bounds__(kOrderBlock) void order_scatter(uint32_t* __restrict__ cost, uint32_t* __restrict__ scan, uint32_t* __restrict__ order, uint32_t n) {
@@ -426,11 +432,15 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, 
 
 uint32_t rt_order_scan_words(void) { return 264u; }
 
-hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots, hipStream_t s) {
+// order_hist (with the frame's epilogue in its first workgroup when `counters` is given: the caller records the frame's end event
+// behind it) and order_scatter, as two calls
+hipError_t rt_launch_order_hist(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots,
+                                unsigned long long* counters, unsigned long long* host, uint32_t words, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
     // Sixteenths from twice the throughput time on, at most 64 tiles (1 / 2 / 4 / 8 times: REF 0.459 / 0.449 / 0.537 / 0.539 ms one at a
     // time, TRI 0.255 / 0.256 / 0.291 / 0.372; 64 against 256 tiles: REF 0.449 against 0.465; a third level of single pixels
-    // changes nothing: profiles/r04/tri_split_sweep16.log, tri_split_sweep64.log).  launch_tri sizes the grid for 256.
+    // changes nothing: profiles/r04/tri_split_sweep16.log, tri_split_sweep64.log; again on round 5's kernel: profiles/r05/tri_split_sweep5.log).
+    // launch_tri sizes the grid for 256.
     uint32_t mult16 = 4u, cap16 = 64u, mult4 = 1u;
 #ifdef RT_TRI_DEV_ENV
     if (const char* e = getenv("RT355_TRI_MULT4")) mult4 = (uint32_t)atoi(e);
@@ -439,19 +449,28 @@ hipError_t rt_launch_order_tiles(uint32_t* cost, uint32_t* scan, uint32_t* order
     if (const char* e = getenv("RT355_TRI_SLOTS")) wave_slots = (uint32_t)atoi(e);
 #endif
     const uint32_t per = rtk::kOrderBlock * rtk::kOrderPerThread, blocks = (n_tiles + per - 1u) / per;
-    hipLaunchKernelGGL(rtk::order_hist, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles, wave_slots, mult16, cap16, mult4);
+    hipLaunchKernelGGL(rtk::order_hist, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles, wave_slots, mult16, cap16, mult4,
+                       counters, host, words);
+    return hipGetLastError();
+}
+hipError_t rt_launch_order_scatter(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    const uint32_t per = rtk::kOrderBlock * rtk::kOrderPerThread, blocks = (n_tiles + per - 1u) / per;
     hipLaunchKernelGGL(rtk::order_scatter, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles);
     return hipGetLastError();
 }
 
-hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
-    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
-    g_rt_kernel_id = heatmap ? RT_KID_HEATMAP : RT_KID_TRIANGLES;
+static bool tri_p16(const RtTriScene& t) {
     // the relinked pair records (rt_api.hip provides them when the scene fits: every instance staged, 16-bit fields)
     bool p16 = t.p16_ok != 0u;
 #ifdef RT_TRI_DEV_ENV
     if (const char* e = getenv("RT355_TRI_P16")) p16 = p16 && atoi(e) != 0;
 #endif
+    return p16;
+}
+
+int rt_tri_stack_form(const RtTriScene& t, int heatmap) {
+    if (!(t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && tri_p16(t))) return 0;
     // Six waves per SIMD (the tiny form) for a caller that keeps frames in flight -- throughput: REF 0.215 -> 0.208 ms per frame,
     // TRI4K 0.542 -> 0.517 --, five (the small form) for one that awaits every frame: such a frame is as long as its longest
     // waves, and those run faster in less company (REF 0.37 against 0.42-0.53 ms; profiles/r05/tri_forms.log).
@@ -461,7 +480,15 @@ hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int he
     if (getenv("RT355_TRI_SMALL")) small = t.tlas_small;
     if (const char* e = getenv("RT355_TRI_SMALL")) small = std::min(small, (uint32_t)atoi(e));
 #endif
-    g_rt_tri_form = (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16) ? (int)small : 0;
+    return (int)small;
+}
+
+hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s) {
+    if (a.n_local_tiles == 0 || a.W == 0) return hipSuccess;
+    g_rt_kernel_id = heatmap ? RT_KID_HEATMAP : RT_KID_TRIANGLES;
+    const bool p16 = tri_p16(t);
+    const uint32_t small = t.form;          // rt_tri_stack_form's answer, which the caller has acted on (t.inst)
+    g_rt_tri_form = (int)small;
     if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 2u) launch_tri<uint16_t, 6, true, 1, true, true, 2>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 1u) launch_tri<uint16_t, 5, true, 1, true, true, 1>(a, t, heatmap, s);
 #ifdef RT_TRI_DEV_ENV

@@ -100,6 +100,27 @@ struct RtInstanceArgs {
 };
 hipError_t rt_launch_apply_instances(const RtInstanceArgs& a, hipStream_t s);
 hipError_t rt_launch_frame_epilogue(unsigned long long* counters, unsigned long long* host, uint32_t words, hipStream_t s);
+// The end of a frame on its stream, as 256 threads of ONE workgroup run it (rt_assemble.hip: frame_epilogue is this and nothing
+// else; rt_triangles.hip: order_hist runs it in its first workgroup, so that an awaited triangle frame ends with one small kernel
+// less in the chain the next frame waits for): the frame's partial ray counters summed, the sum and the frame's fault word
+// (rt_device.h: report_fault) stored where the host reads them without a copy -- pinned, device-visible memory --, and the frame's
+// counter set and control block (queue counts, pixel cursor) zeroed for the next frame that takes this slot.
+#ifdef __HIPCC__
+__device__ __forceinline__ void rt_frame_epilogue_body(unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host, uint32_t words) {
+    const uint32_t t = threadIdx.x;
+    unsigned long long v = t < RT_RAY_COUNTERS ? ctr[t * (RT_RAY_COUNTER_STRIDE / 8u)] : 0ull;
+    const unsigned long long fault = t == 0u ? ctr[1] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);      // RT_RAY_COUNTERS <= 64: all in the first wave
+    __syncthreads();                                                           // every read is done
+    for (uint32_t i = t; i < words; i += 256u) ctr[i] = 0ull;
+    if (t == 0u) {
+        host[0] = v;
+        host[1] = fault;
+        __threadfence_system();
+    }
+}
+#endif
 
 hipError_t rt_launch_prep(const RtPrepArgs& a, hipStream_t s);
 hipError_t rt_launch_trace(const RtFrameArgs& a, const RtLaunchCfg& cfg, hipStream_t s);
