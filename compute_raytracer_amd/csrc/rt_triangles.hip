@@ -471,6 +471,9 @@ static bool tri_p16(const RtTriScene& t) {
 
 int rt_tri_stack_form(const RtTriScene& t, int heatmap) {
     if (!(t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && tri_p16(t))) return 0;
+    // the small forms stage one lookup entry per staged instance record and read nothing else of the per-frame buffers: a lookup
+    // table longer than the instance list (entries a leaf could name that are not staged) keeps the twenty-slot form
+    if (t.n_blas_lookup > t.n_blas) return 0;
     // Six waves per SIMD (the tiny form) for a caller that keeps frames in flight -- throughput: REF 0.215 -> 0.208 ms per frame,
     // TRI4K 0.542 -> 0.517 --, five (the small form) for one that awaits every frame: such a frame is as long as its longest
     // waves, and those run faster in less company (REF 0.37 against 0.42-0.53 ms; profiles/r05/tri_forms.log).

@@ -464,3 +464,29 @@ def test_every_stack_form_of_the_kernel(oracle, n_models, deepen):
         if (n_models, deepen) == (11, 3): assert 0 in seen
     finally:
         r.close()
+
+
+def test_a_lookup_table_longer_than_the_instance_list(oracle):
+    """The small forms of the kernel stage one BLAS-lookup entry per instance record (rt_tri_types.h: RtTriInst) and read no other
+    per-frame buffer.  A host whose lookup table has MORE entries than it has instances -- here every top-level leaf names its
+    instances through the table's second half, a copy of the first -- must get the form that reads the table itself."""
+    scene, mat = triangle_scene(seed=61, n_models=2, rings=5, sectors=7)
+    sky = random_sky(61)
+    W, H, B = 200, 120, 3
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+    try:
+        for frame in range(3):
+            scene.update(0.3)
+            look = np.asarray(scene.frame["blas_lookup"], np.float32)
+            m = len(look)
+            scene.frame["blas_lookup"] = np.concatenate([look, look])
+            t = np.asarray(scene.frame["tlas_nodes"], np.float32).copy()
+            leaf = t[:, 7] > 0
+            t[leaf, 3] += m                                   # the leaves' first lookup slot: into the copy
+            scene.frame["tlas_nodes"] = t
+            r.render()
+            ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
+            assert np.array_equal(r.read_pixels(), ref), (frame, diff_stats(r.read_pixels(), ref))
+            assert r.stats()["rays"] == rays and r.stats()["tri_form"] == 0
+    finally:
+        r.close()
