@@ -29,7 +29,7 @@ SYMBOLS = [
     "rt_write_tri_lookup", "rt_write_blas_lookup", "rt_write_mesh_texture", "rt_select_kernel", "rt_set_mode",
     "rt_set_variant", "rt_set_partition", "rt_tiles_of_rank", "rt_padded_tiles", "rt_render", "rt_wait",
     "rt_read_pixels", "rt_get_stats", "rt_render_to", "rt_assemble_frame", "rt_device_pixels",
-    "rt_build_hierarchy", "rt_filter_plan", "rt_build_flow",
+    "rt_build_hierarchy", "rt_filter_plan", "rt_build_flow", "rt_order_tiles",
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_render_gather", "rt_frame_pixels", "rt_read_frame",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_ctx", "rt_group_render", "rt_group_wait",
     "rt_build_id", "rt_kernel_name", "rt_set_comm_timeout",
@@ -127,6 +127,7 @@ def load():
         "rt_device_pixels": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "rt_build_hierarchy": (ctypes.c_int, [fp, u32, fp, ctypes.POINTER(u32), u32, ctypes.POINTER(u32)]),
         "rt_filter_plan": (ctypes.c_int, [fp, u32, fp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+        "rt_order_tiles": (ctypes.c_int, [vp, ctypes.POINTER(u32), u32, u32, ctypes.POINTER(u32), sz]),
         "rt_comm_unique_id": (ctypes.c_int, [vp]),
         "rt_comm_init": (ctypes.c_int, [vp, vp, u32, u32]),
         "rt_comm_destroy": (ctypes.c_int, [vp]),

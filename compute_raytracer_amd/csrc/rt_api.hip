@@ -1254,6 +1254,34 @@ int rt_build_flow(const float* nodes, uint32_t n_nodes, const uint32_t* roots, u
     return RT_OK;
 }
 
+int rt_order_tiles(rt_ctx* c, const uint32_t* cost, uint32_t n, uint32_t wave_slots, uint32_t* order, size_t cap) {
+    if (!c || (n && !cost) || !order) return fail(RT_ERR_INVALID_ARG, "rt_order_tiles: NULL argument");
+    if (cap < (size_t)n + 2u) return fail(RT_ERR_CAPACITY, "rt_order_tiles: order needs n + 2 entries");
+    if (n > (1u << 26)) return fail(RT_ERR_INVALID_ARG, "rt_order_tiles: more than 2^26 tiles");
+    order[0] = order[1] = 0u;
+    if (n == 0u) return RT_OK;
+    RT_HIP(hipSetDevice(c->device));
+    const size_t cost_bytes = ((size_t)n * 4u + 7u) & ~(size_t)7u, scan_bytes = (size_t)rt_order_scan_words() * 4u;
+    void *d_cost = nullptr, *d_order = nullptr;
+    hipError_t e = hipMalloc(&d_cost, cost_bytes + scan_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_order, ((size_t)n + 2u) * 4u);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cost, 0, cost_bytes + scan_bytes, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cost, cost, (size_t)n * 4u, hipMemcpyHostToDevice, c->stream);
+    uint32_t* const scan = reinterpret_cast<uint32_t*>(static_cast<char*>(d_cost) + cost_bytes);
+    // twice on the same buffers, as consecutive frames of a stream do: the first pass must leave the scan words (and the costs) zero
+    for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+        if (pass) e = hipMemcpyAsync(d_cost, cost, (size_t)n * 4u, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = rt_launch_order_hist(static_cast<uint32_t*>(d_cost), scan, static_cast<uint32_t*>(d_order), n, wave_slots, nullptr, nullptr, 0u, c->stream);
+        if (e == hipSuccess) e = rt_launch_order_scatter(static_cast<uint32_t*>(d_cost), scan, static_cast<uint32_t*>(d_order), n, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(order, d_order, ((size_t)n + 2u) * 4u, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_cost);
+    (void)hipFree(d_order);
+    if (e != hipSuccess) return fail_hip(e, "rt_order_tiles");
+    return RT_OK;
+}
+
 int rt_filter_plan(const float* records, uint32_t n, const float params[24], int* filter_ok, int* signed_filter) {
     if ((n && !records) || !params || !filter_ok || !signed_filter) return fail(RT_ERR_INVALID_ARG, "rt_filter_plan: NULL argument");
     bool ok = false;

@@ -324,8 +324,8 @@ int rt_group_wait(rt_group* g);
 int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* link, uint32_t cap_nodes,
                        uint32_t* n_nodes);
 
-/* Runs the HOST side of the persistent triangle kernel on its own (no device, no context): the relinked copy of the BLAS
- * trees it walks.  `nodes`: the node buffer as rt_write_nodes receives it (8 f32 per node); `roots`: the
+/* Runs the HOST side of the triangle kernel's pair-record forms on its own (no device, no context): the relinked copy of the BLAS
+ * trees they walk.  `nodes`: the node buffer as rt_write_nodes receives it (8 f32 per node); `roots`: the
  * rootNodeIndex of every instance.  Writes *n_pairs records of 16 words {c1.min.xyz, meta1, c1.max.xyz, 0, c2.min.xyz, meta2,
  * c2.max.xyz, 0} -- the two children of an inner node, meta = primitiveCount << 16 | x with x = the leaf's first lookup
  * slot or the inner child's own record number -- ordered most-visited first (by the surface area of the parent's box), and
@@ -333,6 +333,15 @@ int rt_build_hierarchy(const float* records, uint32_t n, float* rec4, uint32_t* 
  * are rendered by the tile-per-wave kernel), RT_ERR_CAPACITY when cap_pairs < *n_pairs (*n_pairs is set either way). */
 int rt_build_flow(const float* nodes, uint32_t n_nodes, const uint32_t* roots, uint32_t n_roots, float* pairs, uint32_t cap_pairs,
                   uint32_t* n_pairs, uint32_t* root_meta);
+
+/* Diagnostic (needs the context's device): the two kernels that turn the per-tile times of an awaited triangle frame into the
+ * next frame's work list (rt_triangles.hip: order_hist, order_scatter), run on `cost[n]` (10 ns ticks) for a
+ * device of `wave_slots` resident waves.  Writes order[0] = tiles to be rendered as four quarters, order[1] = as sixteen 2x2
+ * blocks, order[2 .. 2 + n) = the tiles, longest class first (quarter-octave classes of the cost; within a class any order).
+ * cap: entries of `order`, >= n + 2.  The kernels run twice on the same device buffers (they must leave their scan space and the
+ * costs zero for the next frame); the second pass is returned.  The library calls the same kernels behind every awaited frame of
+ * >= 4096 tiles. */
+int rt_order_tiles(rt_ctx* ctx, const uint32_t* cost, uint32_t n, uint32_t wave_slots, uint32_t* order, size_t cap);
 
 /* Which filter forms a frame of this scene may use (no device needed): *filter_ok = 0 when
  * max(|center| + |radius| over the spheres, |cameraPos|, |lightPosition|) is NaN, infinite or
