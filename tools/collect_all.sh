@@ -22,6 +22,7 @@ want C5 && run C5-fast-v0-n1 RT_EXTRA_PASSES=1 --config C5 --steps 6 --warmup 2
 want REF && run REF-fast-v0-n1 RT_CACHE_PASSES=1 --config REF
 want TRI && run TRI-fast-v0-n1 RT_CACHE_PASSES=1 --config TRI
 want TRI4K && run TRI4K-fast-v0-n1 RT_CACHE_PASSES=1 --config TRI4K
+# (the counting builds link the library's current objects: rebuild them first -- python tools/collect_counts.py --build, in the build container)
 want C3 && python3 tools/collect_counts.py C3 gpurun_out/$RD/collected
 want C5 && python3 tools/collect_counts.py C5 gpurun_out/$RD/collected
 rm -rf gpurun_out/$RD/prof
