@@ -877,6 +877,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         if (c->h_nodes.size() / 8u >= ts.n_nodes) {
             if (ts.n_blas <= 4u && rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 3u, 8u)) ts.tlas_small = 2u;
             else if (rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 4u, 16u)) ts.tlas_small = 1u;
+            else if (rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 8u, 24u)) ts.tlas_small = 3u;
         }
         // two-byte stack entries (count << 14 | x): every meta of the records and of this frame's roots must fit them
         ts.p16_ok = (have_pairs && c->flow.max_count <= 3u && c->flow.max_x <= 16383u) ? 1u : 0u;

@@ -44,20 +44,16 @@ namespace rtk {
 // The sky a path escapes into (RK:122-126) is sampled after the loop, by all lanes of the wave that ended on a miss at once
 // (inside the loop the filter ran for the lanes that missed at THAT bounce while the others waited), through the same one
 // copy of the filter that then samples the fog colour (RK:92): a loop of one or two trips.
-template <int PARK, uint32_t STRIDE> struct Parked;
-template <uint32_t STRIDE> struct Parked<0, STRIDE> {              // no LDS to spare: the values stay where the compiler puts them
-    float r[11];
-    __device__ __forceinline__ explicit Parked(float*) {}
-    template <int K> __device__ __forceinline__ void put(float v) { r[K] = v; }
-    template <int K> __device__ __forceinline__ float get() const { return r[K]; }
-};
+// Slots [0, PARK) are in LDS, the rest stay where the compiler puts them (PARK = 0: no LDS to spare; 11: everything parked;
+// 9: the form whose deeper TLAS stack leaves room for nine -- the reflected direction's y and z ride in registers).
 template <int PARK, uint32_t STRIDE> struct Parked {
-    static_assert(PARK >= 11, "eleven values are parked");
+    static_assert(PARK >= 0 && PARK <= 11, "eleven values are carried");
     typedef volatile __attribute__((address_space(3))) float* lds_f32;   // an LDS address (ds_write_b32 / ds_read_b32 with the slot as
     lds_f32 base;                                                          // immediate offset); volatile: a store is a store, a load a load
+    float r[11];
     __device__ __forceinline__ explicit Parked(float* lane_column) : base((lds_f32)lane_column) {}
-    template <int K> __device__ __forceinline__ void put(float v) { base[K * STRIDE] = v; }
-    template <int K> __device__ __forceinline__ float get() const { return base[K * STRIDE]; }
+    template <int K> __device__ __forceinline__ void put(float v) { if (K < PARK) base[K * STRIDE] = v; else r[K] = v; }
+    template <int K> __device__ __forceinline__ float get() const { return K < PARK ? (float)base[K * STRIDE] : r[K]; }
 };
 // one ray per lane that is here: counted per wave, by one lane, in LDS -- not in a register of every lane
 __device__ __forceinline__ void count_traversal(uint32_t lane, uint32_t* wave_rays) {
@@ -80,15 +76,17 @@ __device__ __forceinline__ float uniform(float v) {               // a value eve
 
 // FLAT: compiled for a one-colour 1x1 sky (A.sky_flat) -- no cube filtering code at all.
 // SMALL: the frame's top-level tree passed rt_tlas_fits (rt_tlas_fit.h).  1: kSmallStack TLAS slots, kSmallNodes staged nodes,
-// and the LDS that frees is the parking place above (7,360 bytes per wave: five waves per SIMD);  2: kTinyStack slots, kTinyNodes
-// nodes, kTinyBlas instance records (6,336 bytes per wave: six waves per SIMD fit a CU's 160 KB).
+// and the LDS that frees is the parking place above (7,364 bytes per wave: five waves per SIMD);  2: kTinyStack slots, kTinyNodes
+// nodes, kTinyBlas instance records (6,340 bytes per wave: six waves per SIMD fit a CU's 160 KB);  3: kMidStack slots, kMidNodes
+// nodes -- every top-level tree twelve instances can have except a degenerate one (2 M - 1 = 23 nodes; depth 8) --, nine of the
+// eleven values parked (7,620 bytes, five waves).
 template <int WAVES, typename STK, int OCC, bool FLAT, bool PACKED, bool PAIRS = false, bool P16 = false, int SMALL = 0>
 __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
     typedef typename std::conditional<PACKED && !P16, uint32_t, STK>::type BSTK;
-    constexpr uint32_t TS = SMALL == 2 ? kTinyStack : (SMALL == 1 ? kSmallStack : kStack);
-    constexpr uint32_t NODES = SMALL == 2 ? kTinyNodes : (SMALL == 1 ? kSmallNodes : kLdsNodes);
+    constexpr uint32_t TS = SMALL == 3 ? kMidStack : (SMALL == 2 ? kTinyStack : (SMALL == 1 ? kSmallStack : kStack));
+    constexpr uint32_t NODES = SMALL == 3 ? kMidNodes : (SMALL == 2 ? kTinyNodes : (SMALL == 1 ? kSmallNodes : kLdsNodes));
     constexpr uint32_t BLAS = SMALL == 2 ? kTinyBlas : kLdsBlas;
-    constexpr int PARK = SMALL ? 11 : 0;
+    constexpr int PARK = SMALL == 3 ? 9 : (SMALL ? 11 : 0);
     __shared__ STK tstacks[TS * 64 * WAVES];
     __shared__ BSTK bstacks[kStack * 64 * WAVES];
     STK* tstack = tstacks + threadIdx.x;
@@ -478,7 +476,7 @@ int rt_tri_stack_form(const RtTriScene& t, int heatmap) {
     // TRI4K 0.542 -> 0.517 --, five (the small form) for one that awaits every frame: such a frame is as long as its longest
     // waves, and those run faster in less company (REF 0.37 against 0.42-0.53 ms; profiles/r05/tri_forms.log).
     uint32_t small = t.tlas_small;
-    if (small == 2u && !t.in_flight) small = 1u;
+    if (small == 2u && !t.in_flight) small = 1u;         // (2 implies 1: three levels within 8 nodes are four within 16)
 #ifdef RT_TRI_DEV_ENV
     if (getenv("RT355_TRI_SMALL")) small = t.tlas_small;
     if (const char* e = getenv("RT355_TRI_SMALL")) small = std::min(small, (uint32_t)atoi(e));
@@ -494,6 +492,7 @@ hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int he
     g_rt_tri_form = (int)small;
     if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 2u) launch_tri<uint16_t, 6, true, 1, true, true, 2>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 1u) launch_tri<uint16_t, 5, true, 1, true, true, 1>(a, t, heatmap, s);
+    else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 3u) launch_tri<uint16_t, 5, true, 1, true, true, 3>(a, t, heatmap, s);
 #ifdef RT_TRI_DEV_ENV
     else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && getenv("RT355_TRI_P16OCC4")) launch_tri<uint16_t, 4, true, 1, true, true>(a, t, heatmap, s);
 #endif
