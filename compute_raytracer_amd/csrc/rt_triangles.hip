@@ -478,8 +478,13 @@ int rt_tri_stack_form(const RtTriScene& t, int heatmap) {
     uint32_t small = t.tlas_small;
     if (small == 2u && !t.in_flight) small = 1u;         // (2 implies 1: three levels within 8 nodes are four within 16)
 #ifdef RT_TRI_DEV_ENV
-    if (getenv("RT355_TRI_SMALL")) small = t.tlas_small;
-    if (const char* e = getenv("RT355_TRI_SMALL")) small = std::min(small, (uint32_t)atoi(e));
+    // RT355_TRI_FORM=k: the form to measure, where the frame's tree qualifies for it (a tree good for 2 is good for 1 and 3, one
+    // good for 1 is good for 3; 0 is always possible).  (RT355_TRI_SMALL of the earlier logs: the same for 0 / 1 / 2.)
+    const char* e = getenv("RT355_TRI_FORM") ? getenv("RT355_TRI_FORM") : getenv("RT355_TRI_SMALL");
+    if (e) {
+        const uint32_t want = (uint32_t)atoi(e), have = t.tlas_small;
+        if (want == 0u || have == 2u || (have == 1u && want != 2u) || (have == 3u && want == 3u)) small = want;
+    }
 #endif
     return (int)small;
 }
