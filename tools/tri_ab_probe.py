@@ -1,4 +1,4 @@
-"""Development probe of the triangle kernels (rt_flow.hip against rt_triangles.hip) on the GPU box: the reference's own
+"""Development probe of the triangle kernel (rt_triangles.hip; variant 0 against 6, or one build or form against another) on the GPU box: the reference's own
 scene (REF), the procedural scene of its size at 1344x846 (TRI) and at 3840x2160 (TRI4K).  Per configuration and
 variant: the frame's sha256 (both kernels must agree), kernel time one frame at a time (hipEvents, min / median) and
 wall time per frame with frames in flight.
