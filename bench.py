@@ -250,6 +250,24 @@ def node_bench(name, scene, mat, sky, cfg, frames):
             shutil.rmtree(tmp, ignore_errors=True)
 
 
+def reduce_over_ranks(torch, dist, elapsed, rays_local, kernel_ms, gather_ms, serial_ms, region_ms, serial_regions):
+    """The contract's "take the MAX over ranks": every time is the slowest rank's, the rays of the frame are the ranks' sum.  Every
+    rank must bring lists of the same lengths (the same --repeats, the same decision whether a serial measurement was made).
+    -> (elapsed, rays_frame, kernel_ms, gather_ms, serial_ms, region_ms, serial_regions); tests/test_tiles_gloo.py runs it over
+    gloo with two and three ranks on the CPU."""
+    t = torch.tensor([elapsed, float(rays_local), kernel_ms, gather_ms, serial_ms or 0.0] + list(region_ms) + list(serial_regions or []),
+                     dtype=torch.float64)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = t.clone()
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    n = len(region_ms)
+    return (float(tmax[0]), int(round(float(tsum[1]))), float(tmax[2]), float(tmax[3]),
+            float(tmax[4]) if serial_ms is not None else None,
+            [float(v) for v in tmax[5:5 + n]],                                   # every region: the slowest rank's time
+            [float(v) for v in tmax[5 + n:]] if serial_regions else serial_regions)
+
+
 def kernel_label(kernel_id):
     """What the library says it launched (rt_stats.kernel_id -- no copy of its dispatch rules here)."""
     from compute_raytracer_amd import abi
@@ -526,20 +544,8 @@ def main():
             scene.buildTopLevel()
 
     if multi:
-        t = torch.tensor([elapsed, float(rays_local), kms / max(kframes, 1), gms / max(kframes, 1), serial_ms or 0.0] + region_ms +
-                         (serial_regions or []), dtype=torch.float64)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        rays_frame = int(round(float(tsum[1])))
-        kernel_ms = float(tmax[2])            # slowest rank's average render time
-        gather_ms = float(tmax[3])
-        serial_ms = float(tmax[4]) if serial_ms is not None else None
-        region_ms = [float(v) for v in tmax[5:5 + len(region_ms)]]             # every region: the slowest rank's time
-        if serial_regions:
-            serial_regions = [float(v) for v in tmax[5 + len(region_ms):]]
+        elapsed, rays_frame, kernel_ms, gather_ms, serial_ms, region_ms, serial_regions = reduce_over_ranks(
+            torch, dist, elapsed, rays_local, kms / max(kframes, 1), gms / max(kframes, 1), serial_ms, region_ms, serial_regions)
         rays_kernel = rays_frame / world      # average rays per launch
     else:
         rays_frame = rays_local

@@ -126,3 +126,35 @@ def test_bench_control_plane_and_gather_to_root(tmp_path, world, W, H):
     mp.spawn(_control_plane_worker, args=(world, port, W, H, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"
+
+
+def _reduce_worker(rank, world, port, result_dir):
+    import importlib.util
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        # rank r: elapsed 1 + r, rays 100 (r + 1), five regions, the serial pair present on every rank
+        got = bench.reduce_over_ranks(torch, dist, 1.0 + rank, 100 * (rank + 1), 0.5 + 0.1 * rank, 0.05 * (world - rank), 2.0 - 0.1 * rank,
+                                      [1.0 + 0.01 * rank * k for k in range(5)], [2.0 + 0.02 * (world - rank) * k for k in range(5)])
+        want = (1.0 + (world - 1), 100 * world * (world + 1) // 2, 0.5 + 0.1 * (world - 1), 0.05 * world, 2.0,
+                [1.0 + 0.01 * (world - 1) * k for k in range(5)], [2.0 + 0.02 * world * k for k in range(5)])
+        ok = all(np.allclose(g, w) for g, w in zip(got, want)) and isinstance(got[1], int)
+        # ... and without a serial measurement (bench.py --serial-steps 0): None stays None, the lists keep their lengths
+        got2 = bench.reduce_over_ranks(torch, dist, 3.0, 7, 0.1, 0.0, None, [0.5 + rank], None)
+        ok = ok and got2[4] is None and got2[6] is None and np.allclose(got2[5], [0.5 + world - 1]) and got2[1] == 7 * world
+        open(os.path.join(result_dir, "rank%d" % rank), "w").write("ok" if ok else "MISMATCH %r %r" % (got, got2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_reduction_over_ranks(tmp_path, world):
+    """bench.py's max-over-ranks / sum-of-rays step (the one piece of its N > 1 path that runs without a GPU), over gloo."""
+    port = _free_port()
+    mp.spawn(_reduce_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / ("rank%d" % r)).read() == "ok"
