@@ -396,7 +396,7 @@ def main():
 
     def step(serial):
         if multi:
-            r.render_gather(root)         # this rank's tiles + RCCL exchange + de-interleave: one C-ABI call
+            r.enqueue_gather(root)        # this rank's tiles + RCCL exchange + de-interleave: one C-ABI call (rt_render_gather)
         else:
             r.enqueue()                   # prep + ray-trace kernel; the library rotates its streams
         if serial:

@@ -192,6 +192,11 @@ class RendererRaytracing:
         if wait:
             abi.check(self._lib.rt_wait(self._ctx), self._ctx)
 
+    def enqueue_gather(self, root=0):
+        """render_gather() without recalculateScene and without the wait -- the counterpart of enqueue() for a group (bench.py
+        times K frames of a scene that is resident before the timed region, with one rank or with many)."""
+        abi.check(self._lib.rt_render_gather(self._ctx, int(root)), self._ctx)
+
     def read_frame(self):
         """The whole W x H frame of the latest render_gather (on a rank that received it)."""
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)
