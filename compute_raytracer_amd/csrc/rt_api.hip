@@ -878,13 +878,16 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             if (ts.n_blas <= 4u && rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 3u, 8u)) ts.tlas_small = 2u;
             else if (rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 4u, 16u)) ts.tlas_small = 1u;
             else if (rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 8u, 24u)) ts.tlas_small = 3u;
+            else if (rt_tlas_fits(c->h_nodes.data(), ts.n_nodes, 8u, 32u)) ts.tlas_small = 4u;
         }
         // two-byte stack entries (count << 14 | x): every meta of the records and of this frame's roots must fit them
         ts.p16_ok = (have_pairs && c->flow.max_count <= 3u && c->flow.max_x <= 16383u) ? 1u : 0u;
-        for (uint32_t i = 0; i < 12u && ts.p16_ok; ++i)
+        for (uint32_t i = 0; i < kInstMax && ts.p16_ok; ++i)
             if ((root_meta[i] >> 16) > 3u || (root_meta[i] & 0xFFFFu) > 16383u) ts.p16_ok = 0u;
-        ts.pairs = (have_pairs && ts.n_blas <= 12u) ? static_cast<const float4*>(c->d_flow.p) : nullptr;
-        for (uint32_t i = 0; i < 12u; ++i) ts.root_meta[i] = root_meta[i];
+        // (13-16 instances: only the form that stages sixteen records can walk the pair records -- the others find a root's meta in
+        // one of TWELVE staged records --, i.e. only a frame whose tree passed a walk above)
+        ts.pairs = (have_pairs && (ts.n_blas <= 12u || ts.tlas_small != 0u)) ? static_cast<const float4*>(c->d_flow.p) : nullptr;
+        for (uint32_t i = 0; i < kInstMax; ++i) ts.root_meta[i] = root_meta[i];
         // which form of the kernel renders the frame (rt_triangles.hip); the small forms take the frame's instance data in their
         // own arguments, in the layout they stage it in
         ts.form = (uint32_t)rt_tri_stack_form(ts, c->kernel == RT_KERNEL_HEATMAP);

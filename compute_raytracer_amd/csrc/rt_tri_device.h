@@ -23,6 +23,7 @@ __device__ __forceinline__ uint32_t sclamp(uint32_t i) { return i > kStack - 1u 
 constexpr uint32_t kSmallStack = 4u, kSmallNodes = 16u;
 constexpr uint32_t kTinyStack = 3u, kTinyNodes = 8u, kTinyBlas = 4u;    // ... and the form for up to four instances
 constexpr uint32_t kMidStack = 8u, kMidNodes = 24u;                      // ... and the one for every tree twelve instances can have but a degenerate one
+constexpr uint32_t kWideNodes = 32u, kWideBlas = 16u;                    // ... and, with kMidStack slots, for the sixteen instances that travel with a frame
 template <uint32_t TS> __device__ __forceinline__ uint32_t tclamp(uint32_t i) { return i > TS - 1u ? TS - 1u : i; }
 
 struct NodeR { v3 lo; float left; v3 hi; float count; };

@@ -6,7 +6,7 @@
 // SMALL forms of the triangle kernel take it: by value, in the kernel's own argument block -- what they stage in LDS, in the
 // layout they stage it in (word 19 of record k: entry k of the lookup table; word 17: the root's relinked meta).  A frame of these
 // forms reads nothing else of the per-frame buffers: no apply_instances kernel in front of it, no version of those buffers to wait for.
-constexpr uint32_t kInstHeadNodes = 24u, kInstBlas = 12u;       // = rt_tri_device.h kMidNodes (the most a small form stages), kLdsBlas
+constexpr uint32_t kInstHeadNodes = 32u, kInstBlas = 16u;       // = rt_tri_device.h kWideNodes, kWideBlas: the most a small form stages
 struct RtTriInst {
     float head[8u * kInstHeadNodes];
     float blas[20u * kInstBlas];
@@ -23,7 +23,8 @@ struct RtTriScene {
     uint32_t n_nodes, n_blas, n_tri, n_tri_lookup, n_blas_lookup, tex_w, tex_h;
     uint32_t packed_ok;        // every node's count, child index and lookup slot fits 16 bits: the BLAS stack may hold (count, left)
     uint32_t tlas_small;       // the host walked this frame's top-level tree (rt_tlas_fit.h): 1 = leaves at most 4 levels down, all nodes among
-                               // the first 16; 2 = at most 3 levels, 8 nodes, 4 instances; 3 = at most 8 levels, 24 nodes; 0 = none of these
+                               // the first 16; 2 = at most 3 levels, 8 nodes, 4 instances; 3 = at most 8 levels, 24 nodes; 4 = 8 levels, 32 nodes;
+                               // 0 = none of these
     uint32_t p16_ok;           // ... and (count << 14 | x) fits 16: leaves of at most 3 triangles, at most 16,384 pair records and lookup slots
     // Work list (rt_triangles.hip: order_hist / order_scatter): tile_order[0] tiles are rendered as four quarters, tile_order[1] as
     // sixteen 2x2 blocks, tile_order[2...] is the order of the tiles (null: every tile whole, in index order); every workgroup
@@ -32,7 +33,7 @@ struct RtTriScene {
     // Relinked copy of the BLAS trees (rt_flow_build.h), when the scene fits it (rt_api.hip: flow_ok; null otherwise): the two
     // children of an inner node as one 64-byte record with packed (count << 16 | x) metas, and per instance the root's meta.
     const float4* pairs;
-    uint32_t root_meta[12];    // instances the tile kernel stages (rt_tri_device.h: kLdsBlas)
+    uint32_t root_meta[16];    // instances the tile kernel stages (rt_tri_device.h: kLdsBlas; kWideBlas in the widest small form)
     const uint32_t* tile_order;
     uint32_t* tile_cost;
     uint32_t form;             // the stack form rt_tri_stack_form chose for this frame (0 / 1 / 2 = SMALL of rt_triangles.hip); forms 1 and 2 read `inst`
@@ -44,7 +45,8 @@ struct RtTriScene {
 };
 
 // Which stack form rt_launch_triangles runs the frame as: 0 twenty TLAS slots, 1 four (five waves per SIMD), 2 three (six waves),
-// 3 eight (five waves).  The caller stores the answer in t.form before the launch and, for 1 - 3, fills t.inst.
+// 3 eight (five waves), 4 eight with sixteen staged instances.  The caller stores the answer in t.form before the launch and, for
+// 1 - 4, fills t.inst.
 int rt_tri_stack_form(const RtTriScene& t, int heatmap);
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);
 uint32_t rt_order_scan_words(void);      // words of scan space rt_launch_order_tiles needs, zeroed once (it leaves them zero)

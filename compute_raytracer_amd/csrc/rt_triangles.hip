@@ -45,7 +45,7 @@ namespace rtk {
 // (inside the loop the filter ran for the lanes that missed at THAT bounce while the others waited), through the same one
 // copy of the filter that then samples the fog colour (RK:92): a loop of one or two trips.
 // Slots [0, PARK) are in LDS, the rest stay where the compiler puts them (PARK = 0: no LDS to spare; 11: everything parked;
-// 9: the form whose deeper TLAS stack leaves room for nine -- the reflected direction's y and z ride in registers).
+// 9 / 6: the forms whose deeper TLAS stack and larger staged head leave room for nine / six -- the rest ride in registers).
 template <int PARK, uint32_t STRIDE> struct Parked {
     static_assert(PARK >= 0 && PARK <= 11, "eleven values are carried");
     typedef volatile __attribute__((address_space(3))) float* lds_f32;   // an LDS address (ds_write_b32 / ds_read_b32 with the slot as
@@ -79,14 +79,15 @@ __device__ __forceinline__ float uniform(float v) {               // a value eve
 // and the LDS that frees is the parking place above (7,364 bytes per wave: five waves per SIMD);  2: kTinyStack slots, kTinyNodes
 // nodes, kTinyBlas instance records (6,340 bytes per wave: six waves per SIMD fit a CU's 160 KB);  3: kMidStack slots, kMidNodes
 // nodes -- every top-level tree twelve instances can have except a degenerate one (2 M - 1 = 23 nodes; depth 8) --, nine of the
-// eleven values parked (7,620 bytes, five waves).
+// eleven values parked (7,620 bytes, five waves);  4: the same stack, kWideNodes nodes and kWideBlas instance records -- whatever
+// sixteen instances, the most that travel with a frame, can have --, six values parked (7,428 bytes, five waves).
 template <int WAVES, typename STK, int OCC, bool FLAT, bool PACKED, bool PAIRS = false, bool P16 = false, int SMALL = 0>
 __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrameArgs A, const RtTriScene T) {
     typedef typename std::conditional<PACKED && !P16, uint32_t, STK>::type BSTK;
-    constexpr uint32_t TS = SMALL == 3 ? kMidStack : (SMALL == 2 ? kTinyStack : (SMALL == 1 ? kSmallStack : kStack));
-    constexpr uint32_t NODES = SMALL == 3 ? kMidNodes : (SMALL == 2 ? kTinyNodes : (SMALL == 1 ? kSmallNodes : kLdsNodes));
-    constexpr uint32_t BLAS = SMALL == 2 ? kTinyBlas : kLdsBlas;
-    constexpr int PARK = SMALL == 3 ? 9 : (SMALL ? 11 : 0);
+    constexpr uint32_t TS = SMALL >= 3 ? kMidStack : (SMALL == 2 ? kTinyStack : (SMALL == 1 ? kSmallStack : kStack));
+    constexpr uint32_t NODES = SMALL == 4 ? kWideNodes : (SMALL == 3 ? kMidNodes : (SMALL == 2 ? kTinyNodes : (SMALL == 1 ? kSmallNodes : kLdsNodes)));
+    constexpr uint32_t BLAS = SMALL == 4 ? kWideBlas : (SMALL == 2 ? kTinyBlas : kLdsBlas);
+    constexpr int PARK = SMALL == 4 ? 6 : (SMALL == 3 ? 9 : (SMALL ? 11 : 0));
     __shared__ STK tstacks[TS * 64 * WAVES];
     __shared__ BSTK bstacks[kStack * 64 * WAVES];
     STK* tstack = tstacks + threadIdx.x;
@@ -468,7 +469,7 @@ static bool tri_p16(const RtTriScene& t) {
 }
 
 int rt_tri_stack_form(const RtTriScene& t, int heatmap) {
-    if (!(t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && tri_p16(t))) return 0;
+    if (!(t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kWideBlas && tri_p16(t))) return 0;
     // the small forms stage one lookup entry per staged instance record and read nothing else of the per-frame buffers: a lookup
     // table longer than the instance list (entries a leaf could name that are not staged) keeps the twenty-slot form
     if (t.n_blas_lookup > t.n_blas) return 0;
@@ -476,6 +477,7 @@ int rt_tri_stack_form(const RtTriScene& t, int heatmap) {
     // TRI4K 0.542 -> 0.517 --, five (the small form) for one that awaits every frame: such a frame is as long as its longest
     // waves, and those run faster in less company (REF 0.37 against 0.42-0.53 ms; profiles/r05/tri_forms.log).
     uint32_t small = t.tlas_small;
+    if (t.n_blas > rtk::kLdsBlas) small = small != 0u ? 4u : 0u;          // 13-16 instances: the form that stages sixteen records (every tree that fits a smaller form fits its 8 levels / 32 nodes)
     if (small == 2u && !t.in_flight) small = 1u;         // (2 implies 1: three levels within 8 nodes are four within 16)
 #ifdef RT_TRI_DEV_ENV
     // RT355_TRI_FORM=k: the form to measure, where the frame's tree qualifies for it (a tree good for 2 is good for 1 and 3, one
@@ -483,7 +485,8 @@ int rt_tri_stack_form(const RtTriScene& t, int heatmap) {
     const char* e = getenv("RT355_TRI_FORM") ? getenv("RT355_TRI_FORM") : getenv("RT355_TRI_SMALL");
     if (e) {
         const uint32_t want = (uint32_t)atoi(e), have = t.tlas_small;
-        if (want == 0u || have == 2u || (have == 1u && want != 2u) || (have == 3u && want == 3u)) small = want;
+        const bool many = t.n_blas > rtk::kLdsBlas;      // (13-16 instances: 4 or 0 only)
+        if (want == 0u || (have != 0u && want == 4u) || (!many && (have == 2u || (have == 1u && want != 2u) || (have == 3u && want == 3u)))) small = want;
     }
 #endif
     return (int)small;
@@ -498,6 +501,7 @@ hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int he
     if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 2u) launch_tri<uint16_t, 6, true, 1, true, true, 2>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 1u) launch_tri<uint16_t, 5, true, 1, true, true, 1>(a, t, heatmap, s);
     else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && small == 3u) launch_tri<uint16_t, 5, true, 1, true, true, 3>(a, t, heatmap, s);
+    else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kWideBlas && p16 && small == 4u) launch_tri<uint16_t, 5, true, 1, true, true, 4>(a, t, heatmap, s);
 #ifdef RT_TRI_DEV_ENV
     else if (t.n_nodes <= 65536u && t.packed_ok && t.pairs && !heatmap && t.n_blas <= rtk::kLdsBlas && p16 && getenv("RT355_TRI_P16OCC4")) launch_tri<uint16_t, 4, true, 1, true, true>(a, t, heatmap, s);
 #endif

@@ -419,17 +419,21 @@ def expected_form(scene, mat):
             left = u32f(nodes[i, 3])
             todo += [(left, d + 1), ((left + 1) & 0xFFFFFFFF, d + 1)]
         return True
+    if len(scene.instances) > 16: return 0
+    if len(scene.instances) > 12: return 4 if fits(8, 32) else 0       # 13-16 instances: the form that stages sixteen records
     if len(scene.instances) <= 4 and fits(3, 8): return 2
     if fits(4, 16): return 1
-    return 3 if fits(8, 24) else 0
+    if fits(8, 24): return 3
+    return 4 if fits(8, 32) else 0
 
 
-@pytest.mark.parametrize("n_models,deepen", [(1, 0), (3, 0), (3, 2), (4, 2), (11, 0), (11, 3), (11, 7)])
+@pytest.mark.parametrize("n_models,deepen", [(1, 0), (3, 0), (3, 2), (4, 2), (11, 0), (11, 3), (11, 7), (14, 0), (15, 1)])
 def test_every_stack_form_of_the_kernel(oracle, n_models, deepen):
     """The host walks every frame's top-level tree (rt_tlas_fit.h) and picks the kernel's stack form (rt_stats.tri_form): up to 4
     instances in a tree of depth <= 3 -- three TLAS slots, six waves per SIMD for frames in flight, five (the four-slot form) for
     awaited ones --, a tree of depth <= 4 within 16 nodes -- four slots, five waves --, depth <= 8 within 24 nodes -- eight slots,
-    nine of the eleven carried values parked --, anything else the reference's twenty.
+    nine of the eleven carried values parked --, 13-16 instances (or 32 nodes) the same stack with sixteen staged records and six
+    parked values --, anything else the reference's twenty.
     n_models + the floor instances, some under extra levels; each awaited and in flight, under a textured sky, against the oracle."""
     scene, mat = triangle_scene(seed=40 + n_models, n_models=n_models, rings=5, sectors=7)
     sky = random_sky(n_models)
@@ -466,6 +470,7 @@ def test_every_stack_form_of_the_kernel(oracle, n_models, deepen):
         if (n_models, deepen) == (1, 0): assert seen == {1, 2}
         if (n_models, deepen) == (11, 3): assert 3 in seen
         if (n_models, deepen) == (11, 7): assert 0 in seen
+        if n_models >= 14: assert 4 in seen
     finally:
         r.close()
 
