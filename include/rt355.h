@@ -107,7 +107,8 @@ typedef struct rt_stats {
     uint32_t tri_form;            /* triangle scenes: the stack form of the latest frame's kernel -- 0: twenty top-level slots,
                                      1: four (a top-level tree of depth <= 4 within 16 nodes), five waves per SIMD, 2: three
                                      (depth <= 3, 8 nodes, <= 4 instances), six waves per SIMD, 3: eight (depth <= 8, 24 nodes),
-                                     five waves */
+                                     five waves, 4: eight with sixteen staged instances (13-16 instances or 32 nodes), five waves
+                                      */
     uint32_t pair_rebuilds;       /* times the library rebuilt its relinked copy of the BLAS trees (a drain + an upload:
                                      a node write reached the trees, or a frame named a root the copy did not know) */
 } rt_stats;
