@@ -434,8 +434,20 @@ def main():
     # Prime every stream and buffer set the library rotates over (the first frame on a stream pays for its
     # hardware queue, the first gather on a buffer set for RCCL's and the runtime's lazy set-up: 7 ms that a
     # warm-up shorter than the rotation would leave inside the timed region), then the W warm-up steps.
-    for _ in range(2 * FLIGHT):
-        step(a.serial)                # (--serial: one at a time here too, so that a profiler sees launches of one kind only)
+    # ... and for at least 40 ms of frames: the device's clocks ramp over tens of milliseconds, and thirteen frames of a 0.2-0.5 ms
+    # configuration are over before they have (the first timed region of the triangle configurations read 4-6 % above the later
+    # ones; C3's thirteen frames are 20 ms and its first region was within 0.5 %).
+    # ... in batches as long as the timed region's (the library's event ring holds 64 frames; an event's first use allocates its
+    # signal, ~10 us each: a first region of 20 frames behind batches of 8 paid for twelve untouched slots, 0.25 ms whatever the
+    # configuration -- 6 % of REF's 4.4 ms region, 0.7 % of C3's).
+    t_prime = time.perf_counter()
+    primed = 0
+    batch = max(2 * FLIGHT, min(a.steps, 64))
+    while primed < 2 * FLIGHT or (time.perf_counter() - t_prime < 0.040 and primed < 4096):
+        for _ in range(batch):
+            step(a.serial)            # (--serial: one at a time here too, so that a profiler sees launches of one kind only)
+        primed += batch
+        r.wait()
     fence()
     for _ in range(a.warmup):
         step(a.serial)
