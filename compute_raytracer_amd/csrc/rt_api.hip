@@ -231,6 +231,19 @@ int rt_create(int device, rt_ctx** out) {
         return fail_hip(err, "rt_create: stream/event/counter setup");
     }
     std::memset(c->h_rays, 0, 16u * RT355_MAX_IN_FLIGHT);
+    // An event's FIRST record allocates its signal (~10 us each, measured through bench.py's first timed region: 0.25 ms for twelve
+    // untouched slots): every event of the ring is recorded once here, so that a host's first frames do not pay for it one by one.
+    for (int i = 0; i < RT355_MAX_IN_FLIGHT && err == hipSuccess; ++i) {
+        if ((err = hipEventRecord(c->ev_prep0[i], c->stream)) != hipSuccess) break;
+        if ((err = hipEventRecord(c->ev_k0[i], c->stream)) != hipSuccess) break;
+        if ((err = hipEventRecord(c->ev_k1[i], c->stream)) != hipSuccess) break;
+        err = hipEventRecord(c->ev_done[i], c->stream);
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+    if (err != hipSuccess) {
+        rt_destroy(c);
+        return fail_hip(err, "rt_create: event warm-up");
+    }
     *out = c;
     return RT_OK;
 }
@@ -728,7 +741,18 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
             for (uint32_t i = 0; i < n_inst; ++i) roots[i] = rt_flow_u32f(c->inst.blas[20u * i + 16u]);
             // (the per-frame head of the node buffer lives in inst.head until a frame carries it: the mirror has it already)
             const bool stale = c->flow_dirty || c->flow.n_nodes != n_nodes;
-            if (stale || !rt_flow_covers(c->flow, roots, n_inst)) {
+            const bool need = stale || !rt_flow_covers(c->flow, roots, n_inst);
+            ++c->flow_frames_since;
+            // A host that invalidates the copy with every frame (it rewrites BLAS nodes per frame: nothing says it may not) would
+            // pay a drain, a host-side rebuild of every tree and an upload per frame for records that live one frame.  Four frames
+            // in a row that each had to rebuild: the node walk (which reads the reference's buffer as written) for the next sixty,
+            // then another try.
+            if (need && c->flow_cooldown > 0u) {
+                --c->flow_cooldown;
+            } else if (need) {
+                c->flow_streak = c->flow_frames_since <= 1u ? c->flow_streak + 1u : 1u;
+                c->flow_frames_since = 0u;
+                if (c->flow_streak >= 4u) { c->flow_cooldown = 60u; c->flow_streak = 0u; }
                 { int rc = drain(c); if (rc != RT_OK) return rc; }
                 std::vector<uint32_t> all(roots, roots + n_inst);
                 if (!stale) all.insert(all.end(), c->flow.roots.begin(), c->flow.roots.end());   // roots already known stay known
@@ -740,7 +764,8 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
                     if (rc != RT_OK) return rc;
                 }
             }
-            have_pairs = c->flow.ok && c->flow.n_pairs != 0u;
+            // usable: current (no write has reached it, the same node count) and knowing every root of this frame
+            have_pairs = !c->flow_dirty && c->flow.ok && c->flow.n_pairs != 0u && c->flow.n_nodes == n_nodes && rt_flow_covers(c->flow, roots, n_inst);
             if (have_pairs) {
                 const uint32_t last = n_nodes - 1u;
                 for (uint32_t i = 0; i < n_inst; ++i)

@@ -134,6 +134,7 @@ struct rt_ctx {
     std::vector<float> h_nodes;                  // mirror of the node buffer (every rt_write_nodes lands here too)
     RtFlow flow;
     bool flow_dirty = true;
+    uint32_t flow_frames_since = 0, flow_streak = 0, flow_cooldown = 0;   // frames since the last rebuild; consecutive frames that rebuilt; frames left on the node walk
     DevBuf d_flow;                               // the pair records
     DevBuf d_tri_dbg;                            // development builds: the triangle kernel's per-workgroup timeline
     uint32_t n_cus = 256;

@@ -499,3 +499,35 @@ def test_a_lookup_table_longer_than_the_instance_list(oracle):
             assert r.stats()["rays"] == rays and r.stats()["tri_form"] == 0
     finally:
         r.close()
+
+
+def test_a_host_that_rewrites_its_trees_every_frame_is_not_made_to_rebuild_the_copy_every_frame(oracle):
+    """The relinked copy of the BLAS trees is invalidated by any write that reaches the nodes it was built from.  A host that
+    rewrites those nodes before EVERY frame (nothing in the interface forbids it) must not pay a drain, a rebuild and an upload per
+    frame: after four such frames in a row the library walks the reference's node buffer for a while (rt_api.hip) -- same pixels."""
+    scene, mat = triangle_scene(seed=71, n_models=2, rings=5, sectors=7)
+    sky = random_sky(71)
+    W, H, B = 200, 120, 3
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
+    L = abi.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    try:
+        r.render()
+        base = r.stats()["pair_rebuilds"]
+        assert base == 1 and r.stats()["tri_form"] == 1
+        nodes = np.ascontiguousarray(scene.pack_blas_nodes(), np.float32)
+        ref, _, rays = oracle.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
+        forms = []
+        for frame in range(10):
+            abi.check(L.rt_write_nodes(r._ctx, 32 * scene.tlasNodesMax, nodes.ctypes.data_as(fp), nodes.shape[0]), r._ctx)   # the same trees, written again
+            r.render()
+            assert np.array_equal(r.read_pixels(), ref), (frame, diff_stats(r.read_pixels(), ref))
+            assert r.stats()["rays"] == rays
+            forms.append(r.stats()["tri_form"])
+        assert r.stats()["pair_rebuilds"] == base + 3           # four frames in a row rebuilt (the first frame's build included), then the node walk
+        assert forms[:3] == [1, 1, 1] and set(forms[3:]) == {0}
+        for frame in range(3):                                  # the host stops rewriting: the copy stays stale for the cool-down, pixels right
+            r.render()
+            assert np.array_equal(r.read_pixels(), ref)
+    finally:
+        r.close()
