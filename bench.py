@@ -388,14 +388,42 @@ def main():
     r.set_mode(a.mode == "strict")
     r.set_variant(a.variant)
     root = 0 if a.gather == "root" else -1
+    # How the ranks' rows reach the frame: RCCL inside the library.  If rt_comm_init is REFUSED on any rank (two ranks rehearsing on
+    # one device: RCCL's duplicate-device rule; a node whose RCCL cannot initialise), every rank falls back TOGETHER to its rows read
+    # back and all-gathered over the control plane (gloo), every frame awaited -- slow, and said so in the line (`exchange`,
+    # config.parallelism): a labelled curve instead of no record.  The rendering is the library's either way.
+    exchange = "rccl" if multi else None
+    exchange_error = None
+    host_frame = [None]
     if multi:
         ids = [rt.RendererRaytracing.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        r.comm_init(ids[0], rank, world)              # collective: ncclCommInitRank on this rank's GPU
+        try:
+            r.comm_init(ids[0], rank, world)          # collective: ncclCommInitRank on this rank's GPU
+        except rt.abi.RtError as e:
+            exchange_error = "rank %d: %s" % (rank, e)
+        errs = [None] * world
+        dist.all_gather_object(errs, exchange_error)
+        if any(errs):
+            exchange, exchange_error = "host", next(e for e in errs if e)
+            r.close()
+            r = rt.RendererRaytracing(W, H, scene, device=local_rank, maxBounces=B, rank=rank, world=world)   # the partition without the communicator
+            r.initialize(sky, mat)
+            r.set_mode(a.mode == "strict")
+            r.set_variant(a.variant)
+            import numpy as np
+            host_rows = np.zeros((tiles.padded_tiles(H, world) * 8, W, 4), dtype=np.uint8)
     r.recalculateScene()   # uploads: scene resident in HBM before anything is timed
 
     def step(serial):
-        if multi:
+        if exchange == "host":
+            r.enqueue(); r.wait()
+            pix = r.read_pixels()                     # this rank's tiles, in order (only the frame's last tile can be short)
+            host_rows[:pix.shape[0]] = pix
+            g = tiles.all_gather_frame(torch.from_numpy(host_rows), W, H)
+            if rank == 0 or root < 0:
+                host_frame[0] = tiles.assemble_torch(g, W, H, world)
+        elif multi:
             r.enqueue_gather(root)        # this rank's tiles + RCCL exchange + de-interleave: one C-ABI call (rt_render_gather)
         else:
             r.enqueue()                   # prep + ray-trace kernel; the library rotates its streams
@@ -469,7 +497,7 @@ def main():
     gold = None if tri else golden_frame(name)
     tri_frame = r.read_pixels() if tri and not multi and rank == 0 else None
     if gold is not None and (not multi or rank == 0 or root < 0):
-        frame = r.read_frame() if multi else r.read_pixels()
+        frame = host_frame[0].numpy() if exchange == "host" else (r.read_frame() if multi else r.read_pixels())
         check = {"sha256_matches_oracle_frame": hashlib.sha256(frame.tobytes()).hexdigest() == gold["sha256"],
                  "golden": "tests/golden/frames.json[%s]" % ("C3" if name == "C4" else name)}
 
@@ -719,6 +747,8 @@ def main():
                        "mode": a.mode, "variant": a.variant, "rays_per_frame": rays_frame,
                        "frames_in_flight": 1 if a.serial else FLIGHT,
                        "parallelism": "row-tiles x%d%s" % (world, "" if not multi else
+                                                           " + rows read back and all-gathered over gloo, every frame awaited (FALLBACK: rt_comm_init was refused)"
+                                                           if exchange == "host" else
                                                            " + RCCL %s inside librt355 (rt_render_gather)" %
                                                            ("gather to rank 0" if root == 0 else "all-gather"))},
             "roofline": roof,
@@ -730,6 +760,9 @@ def main():
         }
         if multi:
             out["gather_ms_avg"] = gather_ms
+            out["exchange"] = exchange
+            if exchange_error:
+                out["exchange_error"] = exchange_error
         out["scaling_note"] = ("ms_per_step / value: frames enqueued back to back (up to %d in flight); serial_ms_per_step / serial_value: every frame "
                                "awaited, the reference's loop (src/app.ts:124-127).  BASELINE.json's >= 6x at 8 GPUs is claimed for the frames-in-flight "
                                "figure; DESIGN.md 6 gives the emulated per-rank times for both." % FLIGHT)

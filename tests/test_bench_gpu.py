@@ -92,6 +92,21 @@ def test_bench_distributed_path_with_one_rank():
         assert "rt_render_gather" in d["config"]["parallelism"] and "gather_ms_avg" in d
 
 
+def test_bench_two_ranks_rehearsed_on_one_device():
+    """The driver's N > 1 command on a one-GPU box: `bench.py --gpus 2` starts its two ranks itself (a child
+    torch.distributed.run), RT355_BENCH_ONE_DEVICE puts both on device 0.  RCCL refuses two ranks of one device: every rank
+    falls back TOGETHER to the labelled host exchange (rows read back, all-gathered over gloo), and the frame the two ranks'
+    interleaved tiles make -- 135 tiles: 68 and 67, ragged -- is the oracle's.  (Should RCCL ever accept it: the RCCL path, same frame.)"""
+    d, err = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C2", "--no-cpu-baseline", "--repeats", "1",
+                       env={"RT355_BENCH_ONE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["exchange"] in ("host", "rccl")
+    if d["exchange"] == "host":
+        assert "rt_comm_init" in d["config"]["parallelism"] and "FALLBACK" in d["config"]["parallelism"]
+        assert "ncclCommInitRank" in d["exchange_error"]
+    assert d["frame_check"]["sha256_matches_oracle_frame"] is True
+    assert d["config"]["rays_per_frame"] == json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))["C2"]["rays"]
+
+
 def test_smoke_entry_point():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
