@@ -30,6 +30,9 @@ Prints ONE JSON line on rank 0.
     The ALGORITHMIC rate of the reference's test-every-sphere loop (25 flop x N x rays / time) is kept
     apart as `algorithmic_speedup_vs_bruteforce`.  The HBM fraction the north_star asks for is `hbm`.
   * frame_check: sha256 of the last timed frame against tests/golden/frames.json (the oracle's frame).
+  * exchange (N > 1): "rccl" -- the product's path -- or "host": rt_comm_init was refused on some rank (exchange_error says why)
+    and every rank fell back together to its rows read back and all-gathered over gloo, every frame awaited.  A record with
+    its cause in it, not a figure of the product's.
   * cpu_baseline: the CPU oracle (the repository's scalar restatement of the shader: kind "port") on a
     bounded sample of the same frame.
 """

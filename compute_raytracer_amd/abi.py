@@ -38,7 +38,7 @@ SYMBOLS = [
 
 # rt_kernel_id (include/rt355.h): which kernel form rendered a frame
 KERNEL_IDS = {0: "none", 1: "literal", 2: "brute_single", 3: "brute_pipeline", 4: "hierarchy_8", 5: "hierarchy_12",
-              6: "hierarchy_16", 7: "hierarchy_global", 8: "triangles", 9: "heatmap"}
+              6: "hierarchy_16", 7: "hierarchy_global", 8: "triangles", 9: "heatmap", 10: "triangles_roles"}
 
 
 class RtStats(ctypes.Structure):

@@ -165,6 +165,7 @@ const char* rt_kernel_name(int id) {
         case RT_KID_HIERARCHY_GLOBAL: return "bvh_pixels<global>";
         case RT_KID_TRIANGLES: return "trace_triangles";
         case RT_KID_HEATMAP: return "heatmap_triangles";
+        case RT_KID_TRIANGLES_ROLES: return "trace_roles";
         default: return "none";
     }
 }
@@ -225,12 +226,13 @@ int rt_create(int device, rt_ctx** out) {
     if (err != hipSuccess ||
         (err = hipMalloc(reinterpret_cast<void**>(&c->d_rays), kCtrlBytes * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
         (err = hipMemset(c->d_rays, 0, kCtrlBytes * RT355_MAX_IN_FLIGHT)) != hipSuccess ||
-        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), 16u * RT355_MAX_IN_FLIGHT,
+        (err = hipHostMalloc(reinterpret_cast<void**>(&c->h_rays), 16u * RT355_MAX_IN_FLIGHT + 8u * kStreams,
                              hipHostMallocDefault)) != hipSuccess) {
         rt_destroy(c);
         return fail_hip(err, "rt_create: stream/event/counter setup");
     }
-    std::memset(c->h_rays, 0, 16u * RT355_MAX_IN_FLIGHT);
+    std::memset(c->h_rays, 0, 16u * RT355_MAX_IN_FLIGHT + 8u * kStreams);
+    c->h_split = c->h_rays + 2u * RT355_MAX_IN_FLIGHT;
     // An event's FIRST record allocates its signal (~10 us each, measured through bench.py's first timed region: 0.25 ms for twelve
     // untouched slots): every event of the ring is recorded once here, so that a host's first frames do not pay for it one by one.
     for (int i = 0; i < RT355_MAX_IN_FLIGHT && err == hipSuccess; ++i) {
@@ -995,7 +997,11 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
 #endif
         if (order_set >= 0) {
             ts.tile_cost = static_cast<uint32_t*>(c->d_tile_cost[order_set].p);
-            if (c->order_tiles[order_set] == order_n) ts.tile_order = static_cast<const uint32_t*>(c->d_tile_order[order_set].p);
+            if (c->order_tiles[order_set] == order_n) {
+                ts.tile_order = static_cast<const uint32_t*>(c->d_tile_order[order_set].p);
+                // does that list split tiles?  Then the kernel whose parts' idle lanes trace ahead (the word may be a frame old)
+                ts.roles = __atomic_load_n(&c->h_split[order_set], __ATOMIC_RELAXED) != 0ull ? 1u : 0u;
+            }
 #ifdef RT355_DEV_EXPORTS
             if (getenv("RT355_TRI_NOLIST")) ts.tile_order = nullptr;
 #endif
@@ -1024,7 +1030,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
         uint32_t* const cost = static_cast<uint32_t*>(c->d_tile_cost[order_set].p);
         uint32_t* const scan = reinterpret_cast<uint32_t*>(static_cast<char*>(c->d_tile_cost[order_set].p) + c->d_tile_cost[order_set].cap);
         uint32_t* const list = static_cast<uint32_t*>(c->d_tile_order[order_set].p);
-        RT_HIP(rt_launch_order_hist(cost, scan, list, order_n, c->wave_slots, nullptr, nullptr, 0u, s));
+        RT_HIP(rt_launch_order_hist(cost, scan, list, order_n, c->wave_slots, nullptr, nullptr, 0u, c->h_split + order_set, s));
         RT_HIP(rt_launch_order_scatter(cost, scan, list, order_n, s));
         c->order_tiles[order_set] = order_n;
     }
@@ -1300,7 +1306,7 @@ int rt_order_tiles(rt_ctx* c, const uint32_t* cost, uint32_t n, uint32_t wave_sl
     // twice on the same buffers, as consecutive frames of a stream do: the first pass must leave the scan words (and the costs) zero
     for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
         if (pass) e = hipMemcpyAsync(d_cost, cost, (size_t)n * 4u, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = rt_launch_order_hist(static_cast<uint32_t*>(d_cost), scan, static_cast<uint32_t*>(d_order), n, wave_slots, nullptr, nullptr, 0u, c->stream);
+        if (e == hipSuccess) e = rt_launch_order_hist(static_cast<uint32_t*>(d_cost), scan, static_cast<uint32_t*>(d_order), n, wave_slots, nullptr, nullptr, 0u, nullptr, c->stream);
         if (e == hipSuccess) e = rt_launch_order_scatter(static_cast<uint32_t*>(d_cost), scan, static_cast<uint32_t*>(d_order), n, c->stream);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(order, d_order, ((size_t)n + 2u) * 4u, hipMemcpyDeviceToHost, c->stream);

@@ -101,6 +101,7 @@ struct rt_ctx {
     unsigned long long* d_rays = nullptr;
     float4* d_queue = nullptr;             // path queue of the two-kernel pipeline
     size_t queue_cap = 0;                  // entries
+    unsigned long long* h_split = nullptr; // behind h_rays, per stream: the number of tiles the stream's current work list renders in parts (order_hist writes it)
     unsigned long long* h_rays = nullptr;  // pinned, device-visible: per frame in flight {rays, fault word}, written by the frame's epilogue kernel
     // the reference's triangle scene (RR:169-229), device copies in the reference's byte layouts
     struct DevBuf { void* p = nullptr; size_t cap = 0; size_t used = 0; };

@@ -41,6 +41,8 @@ struct RtTriScene {
     uint32_t in_flight;        // the caller keeps frames in flight (rt_api.hip: pipelined_hint): throughput over latency
     unsigned long long* dbg;   // development builds (tools/tri_timeline.py): per workgroup {start, end (100 MHz ticks), tile << 8 | part}; null: off
     uint32_t prio;             // development builds: wave priority of the head of the work list (rt_triangles.hip)
+    uint32_t roles;            // the frame's work list splits tiles (the caller knows from the pinned word order_hist leaves): forms 1 and 3 then run as trace_roles (rt_triangles.hip)
+    uint32_t cost_mul4, cost_mul16;   // ... whose quarters / sixteenths leave their time x this / 8 in tile_cost
     uint32_t xcd_rows;         // set by the launch (no work list): workgroup b renders row (b % 8) + 8 (b / 8 / tiles per row) -- a row per XCD
 };
 
@@ -51,6 +53,7 @@ int rt_tri_stack_form(const RtTriScene& t, int heatmap);
 hipError_t rt_launch_triangles(const RtFrameArgs& a, const RtTriScene& t, int heatmap, hipStream_t s);
 uint32_t rt_order_scan_words(void);      // words of scan space rt_launch_order_tiles needs, zeroed once (it leaves them zero)
 hipError_t rt_launch_order_hist(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots,
-                                unsigned long long* counters, unsigned long long* host, uint32_t words, hipStream_t s);   // + the frame's epilogue
+                                unsigned long long* counters, unsigned long long* host, uint32_t words, unsigned long long* split_out,
+                                hipStream_t s);   // (+ the frame's epilogue); split_out: pinned word that receives the number of tiles the list splits, or null
 hipError_t rt_launch_order_scatter(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, hipStream_t s);
 hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* lookup, uint32_t n_slots, uint32_t n_tri, hipStream_t s);

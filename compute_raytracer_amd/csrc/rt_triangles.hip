@@ -242,6 +242,222 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void trace_triangles(const RtFrame
     }
 }
 
+// ---- the kernel for AWAITED frames with a work list: a split tile's idle lanes trace ahead ---------------------------------
+// An awaited frame is as long as its longest waves, and those are the quarters and sixteenths of its longest tiles: 16 or 4
+// lanes whose paths are 2 x bounces DEPENDENT traversals each.  But only almost: the shadow ray of bounce b (RK:153) and the
+// reflection ray of bounce b + 1 (RK:114) both start from what the hit of bounce b gives -- the point, the normal -- and
+// neither needs the other.  In a quarter 48 lanes idle, in a sixteenth 60.  Here lane k + n of a part of n pixels is the HELPER
+// of lane k: while the owner walks the shadow ray the helper walks the next reflection ray, through the same call of the
+// traversal (one copy of its code, each lane its own stacks), and hands the hit back through LDS -- the helper's own parking
+// column is the mailbox: slots 0-5 the ray, 6 whether there is one; then 0-4 the hit.  A path of B bounces is then 1 + B traversals long
+// instead of 2 B (each as long as the longer of the two), and so is the wave.  No ray is cast that the reference does not cast
+// (the owner posts the next reflection ray only when the bounce limit leaves room for it: the loop of RK:113 would cast it), none is cast twice:
+// the ray counter stays exact.  A whole tile has no idle lanes: its owners walk reflection ray and shadow ray in turn, through
+// the same one call.  Every floating-point expression is the one of trace_triangles, in its order.
+// The shading of a hit before its shadow ray is cast (RK:129-135, RK:147-162; the block of trace_triangles): what survives the
+// shadow ray goes to the parked slots 4-10; -> the hit point and the shadow ray's direction.
+template <class PK>
+__device__ __forceinline__ void shade_hit(const RtTriScene& T, const TriLds& L, const Scene& sc, PK& pk, const TriHit& h, v3 o, v3 d, v3& ro, v3& sdir) {
+    const v3 normal = hit_normal(T, h, L.blas + 20u * (uint32_t)h.blas);
+    const Albedo s = hit_albedo(T, h.tri, h.u, h.v);
+    ro = add(o, scale(h.t, d));                                                  // RK:129
+    const v3 rd = normalize(reflect(d, normal));                                 // RK:130
+    sdir = normalize(sub(ro, sc.lightPos));                                      // RK:147
+    const float distance = length(sdir);                                         // RK:148
+    const float power = clampf(dot(normal, V(-sdir.x, -sdir.y, -sdir.z)), sc.minIntensity, 1.0f);   // RK:160
+    const float cap = sc.lightIntensity / (sc.lightIntensity + distance);                           // RK:161
+    pk.template put<4>(power * cap);                                                                // RK:162
+    const v3 diffuseColor = scale(s.w, s.rgb);                                   // RK:133
+    const v3 samplerColor = scale(1.0f - s.w, tex2d_sample(T, s.u, s.v));        // RK:134
+    const v3 albedo = add(diffuseColor, samplerColor);                           // RK:135, the sum
+    pk.template put<5>(albedo.x); pk.template put<6>(albedo.y); pk.template put<7>(albedo.z);
+    pk.template put<8>(rd.x); pk.template put<9>(rd.y); pk.template put<10>(rd.z);
+}
+// The shadow ray's verdict (RK:155-166) and the running mean (RK:120, RK:135-136) into the parked colour.
+template <class PK>
+__device__ __forceinline__ void blend_bounce(const Scene& sc, PK& pk, const TriHit& sh, v3 sdir, v3 ro, float affect, float sum) {
+    float intensity = sc.minIntensity;                                           // RK:165
+    if (sh.tri >= 0) {                                                           // RK:155
+        const v3 hp = add(sc.lightPos, scale(sh.t, sdir));                       // RK:156
+        const v3 dv = sub(hp, ro);                                               // RK:157-159: see light_term (rt_device.h)
+        if (dot(dv, dv) < 0x1.a36e2cp-16f) intensity = pk.template get<4>();
+    }
+    const float next = affect + sum;                                             // RK:120
+    const v3 albedo = V(pk.template get<5>(), pk.template get<6>(), pk.template get<7>());
+    const v3 color = V(pk.template get<0>(), pk.template get<1>(), pk.template get<2>());
+    const v3 blended = scale(intensity, albedo);                                 // RK:135
+    const v3 mixed = divs(add(scale(sum, color), scale(affect, blended)), next); // RK:136
+    pk.template put<0>(mixed.x); pk.template put<1>(mixed.y); pk.template put<2>(mixed.z);
+}
+
+template <typename STK, int OCC, bool FLAT, int SMALL>
+__global__ __launch_bounds__(64, OCC) void trace_roles(const RtFrameArgs A, const RtTriScene T) {
+    constexpr int WAVES = 1;
+    constexpr uint32_t TS = SMALL >= 3 ? kMidStack : (SMALL == 2 ? kTinyStack : (SMALL == 1 ? kSmallStack : kStack));
+    constexpr uint32_t NODES = SMALL == 4 ? kWideNodes : (SMALL == 3 ? kMidNodes : (SMALL == 2 ? kTinyNodes : (SMALL == 1 ? kSmallNodes : kLdsNodes)));
+    constexpr uint32_t BLAS = SMALL == 4 ? kWideBlas : (SMALL == 2 ? kTinyBlas : kLdsBlas);
+    constexpr int PARK = SMALL == 4 ? 6 : (SMALL == 3 ? 9 : (SMALL ? 11 : 0));
+    static_assert(PARK >= 7, "the mailbox is seven parked slots of the helper's column");
+    __shared__ STK tstacks[TS * 64];
+    __shared__ STK bstacks[kStack * 64];
+    STK* tstack = tstacks + threadIdx.x;
+    STK* bstack = bstacks + threadIdx.x;
+    constexpr uint32_t stride = 64;
+    __shared__ float4 s_nodes[2 * NODES];
+    __shared__ float s_blas[20 * BLAS];
+    __shared__ float s_park[PARK * 64];
+    __shared__ uint32_t s_rays[1];
+    if (threadIdx.x == 0u) s_rays[0] = 0u;
+    const TriLds L = stage_head<WAVES, NODES, BLAS, true>(T, s_nodes, s_blas);
+
+    const uint32_t lane = threadIdx.x;
+    const uint64_t clk0 = wall_clock64();
+    const uint32_t groups_x = (A.W + 7u) / 8u;
+    const uint32_t n_tiles = groups_x * A.n_local_tiles;
+    uint32_t tile = blockIdx.x, part = 4u;
+    if (T.tile_order) {
+        const uint32_t s4 = T.tile_order[0], s16 = T.tile_order[1];
+        const uint32_t* list = T.tile_order + 2;
+        uint32_t i = blockIdx.x;
+        if (i < 16u * s16) { tile = list[i >> 4]; part = 16u + (i & 15u); }
+        else if ((i -= 16u * s16) < 4u * s4) { tile = list[s16 + (i >> 2)]; part = i & 3u; }
+        else if ((i -= 4u * s4) < n_tiles - s16 - s4) tile = list[s16 + s4 + i];
+        else return;
+    }
+    const uint32_t by = tile / groups_x, bx = tile - by * groups_x;
+    const bool split = part != 4u;
+    const uint32_t owners = part < 4u ? 16u : (part >= 16u ? 4u : 64u);
+    if (split && lane >= 2u * owners) return;
+    const bool helper = split && lane >= owners;
+    const uint32_t ol = helper ? lane - owners : lane;               // the pixel's lane: a helper leaves where its owner leaves
+    uint32_t px = ol & 7u, row = ol >> 3;
+    if (part < 4u) { px = 4u * (part & 1u) + (ol & 3u); row = 4u * (part >> 1) + (ol >> 2); }
+    else if (part >= 16u) { px = 2u * (part & 3u) + (ol & 1u); row = 2u * ((part >> 2) & 3u) + (ol >> 1); }
+    const uint32_t x = bx * 8u + px;
+    const uint32_t y = (A.tile_first + by * A.tile_step) * 8u + row;
+    if (x >= A.W || y >= A.H) return;
+
+    Parked<PARK, stride> pk(s_park + lane);                                             // an owner's carried values (as in trace_triangles)
+    Parked<PARK, stride> mb(s_park + (helper ? lane : (split ? lane + owners : lane))); // the pair's mailbox: the helper's column
+    const Scene sc = unpack_scene(A);
+    float dummy = 0.0f;
+    bool missed = false;
+    if (!helper) {
+        pk.template put<0>(1.0f); pk.template put<1>(1.0f); pk.template put<2>(1.0f);   // color = (1, 1, 1), RK:103
+        pk.template put<3>(0.0f);                                                        // dist, RK:116-118
+    }
+    // One loop, one call of the traversal per trip.  An owner's trips: the primary ray, then per bounce the shadow ray -- and, in a
+    // whole tile, where nobody walks it for him, the next reflection ray in a trip of its own.  A helper's: whatever its mailbox holds.
+    v3 o = sc.cameraPos, d = V(0.0f, 0.0f, 0.0f), ro = V(0.0f, 0.0f, 0.0f);
+    bool act = false, shadow = false;
+    uint32_t bounce = 0u;
+    float affect = 1.0f, sum = 0.0f;
+    if (!helper) {
+        d = primary_dir(A, sc, x, y);
+        act = sc.bounces > 0u;                                                           // RK:113
+        if (split) mb.template put<6>(0.0f);                                             // nothing for the helper yet
+    }
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        if (helper) {
+            act = mb.template get<6>() != 0.0f;
+            if (act) {
+                o = V(mb.template get<0>(), mb.template get<1>(), mb.template get<2>());
+                d = V(mb.template get<3>(), mb.template get<4>(), mb.template get<5>());
+            }
+        }
+        if (__ballot(act) == 0ull) break;
+        TriHit h; h.t = 0.0f; h.u = h.v = 0.0f; h.tri = -1; h.blas = -1;
+        if (act) {
+            h = trace_tlas<false, STK, true, true, true, TS>(T, L, o, d, tstack, bstack, stride, dummy);   // RK:114 / RK:153
+            count_traversal(lane, &s_rays[0]);
+        }
+        if (helper && act) {                                       // the hit goes back to the owner
+            mb.template put<0>(h.t); mb.template put<1>(h.u); mb.template put<2>(h.v);
+            mb.template put<3>(__int_as_float(h.tri)); mb.template put<4>(__int_as_float(h.blas));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!helper && act) {
+            affect = uniform(affect); sum = uniform(sum);          // every owner of the wave is at the same bounce, in the same kind of trip
+            bool have = !shadow;                                   // h is the hit of a reflection (or the primary) ray
+            if (shadow) {                                          // h is the shadow ray's: RK:155-166, then the blend RK:135-140
+                blend_bounce(sc, pk, h, d, ro, affect, sum);
+                sum = affect + sum;                                                      // RK:140 (next, RK:120)
+                affect = affect / 2.0f;                                                  // RK:139
+                bounce += 1u;
+                shadow = false;
+                o = ro;                                                                  // the next reflection ray (RK:129-130) ...
+                d = V(pk.template get<8>(), pk.template get<9>(), pk.template get<10>());
+                if (bounce >= sc.bounces) act = false;                                   // RK:113
+                else if (split) {                                                        // ... which the helper has walked meanwhile
+                    h.t = mb.template get<0>(); h.u = mb.template get<1>(); h.v = mb.template get<2>();
+                    h.tri = __float_as_int(mb.template get<3>()); h.blas = __float_as_int(mb.template get<4>());
+                    have = true;
+                }
+            }
+            if (have && act) {
+                if (h.tri < 0) {                                                         // RK:122-126: sampled after the loop
+                    pk.template put<4>(d.x); pk.template put<5>(d.y); pk.template put<6>(d.z);
+                    pk.template put<7>(affect); pk.template put<8>(sum);
+                    missed = true; act = false;
+                    if (split) mb.template put<6>(0.0f);
+                } else {
+                    if (bounce == 0u) pk.template put<3>(h.t);                           // RK:116-118
+                    v3 sdir;
+                    shade_hit(T, L, sc, pk, h, o, d, ro, sdir);
+                    if (split) {                                                         // the helper's next ray, if the loop of RK:113 casts one
+                        if (bounce + 1u < sc.bounces) {
+                            mb.template put<0>(ro.x); mb.template put<1>(ro.y); mb.template put<2>(ro.z);
+                            mb.template put<3>(pk.template get<8>()); mb.template put<4>(pk.template get<9>()); mb.template put<5>(pk.template get<10>());
+                            mb.template put<6>(1.0f);
+                        } else mb.template put<6>(0.0f);
+                    }
+                    o = sc.lightPos; d = sdir; shadow = true;                            // RK:153
+                }
+            }
+        }
+    }
+    if (helper) return;
+    v3 color = V(pk.template get<0>(), pk.template get<1>(), pk.template get<2>());
+    const float dist = pk.template get<3>();
+    v3 fog = V(0.0f, 0.0f, 0.0f);
+    v3 dir = V(0.0f, 0.0f, 0.0f);
+    float affect_e = 0.0f, sum_e = 0.0f;
+    if (missed) {
+        dir = V(pk.template get<4>(), pk.template get<5>(), pk.template get<6>());
+        affect_e = pk.template get<7>(); sum_e = pk.template get<8>();
+    }
+    const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t px_e = lane_e & 7u, row_e = lane_e >> 3;
+    if (part < 4u) { px_e = 4u * (part & 1u) + (lane_e & 3u); row_e = 4u * (part >> 1) + (lane_e >> 2); }
+    else if (part >= 16u) { px_e = 2u * (part & 3u) + (lane_e & 1u); row_e = 2u * ((part >> 2) & 3u) + (lane_e >> 1); }
+    const RtFrameArgs& Ae = reread_first_kernarg();
+    const Scene sce = unpack_scene(Ae);
+    const uint32_t x_e = bx * 8u + px_e;
+    const uint32_t y_e = (Ae.tile_first + by * Ae.tile_step) * 8u + row_e;
+#pragma unroll 1
+    for (int k = missed ? 0 : 1; k < 2; ++k) {
+        if (k == 1) dir = primary_dir(Ae, sce, x_e, y_e);
+        const v3 sky = scale(sce.minIntensity, cube_sample<FLAT ? 1 : 0, true>(Ae, dir));
+        if (k == 0) color = divs(add(scale(sum_e, color), scale(affect_e, sky)), affect_e + sum_e);   // RK:120, 125
+        else fog = sky;
+    }
+    const uint32_t opix = (by * 8u + row_e) * Ae.W + x_e;
+    reinterpret_cast<uint32_t*>(Ae.out)[opix] = compose_pixel_sky(fog, color, dist);   // RK:91-98
+    if (lane_e == (uint32_t)__builtin_amdgcn_readfirstlane((int)lane_e)) count_wave_rays(Ae.rays, s_rays[0]);
+#ifdef RT_TRI_DEV_ENV
+    if (T.dbg && threadIdx.x == 0u) {
+        T.dbg[3u * blockIdx.x] = clk0; T.dbg[3u * blockIdx.x + 1u] = wall_clock64(); T.dbg[3u * blockIdx.x + 2u] = ((unsigned long long)tile << 8) | part;
+    }
+#endif
+    // (what a part leaves for the next list: its time scaled to what the whole tile would take as one wave of 64 owners that walk
+    // both rays of a bounce themselves -- T.cost_mul16 / cost_mul4, in eighths)
+    if (T.tile_cost && threadIdx.x == 0u) {
+        const uint32_t dt = (uint32_t)(wall_clock64() - clk0);
+        atomicMax(&T.tile_cost[tile], part >= 16u ? (dt * T.cost_mul16) >> 3 : (part < 4u ? (dt * T.cost_mul4) >> 3 : dt));
+    }
+}
+
 // ---- the order of the next frame's tiles ------------------------------------------------------------------
 // The frame is a grid of independent tiles, one wave each, whose costs differ by more than an order of magnitude (a sky tile:
 // one ray per pixel; a tile between two mirrors: 2 x bounces dependent traversals by 64 diverging lanes), and the hardware
@@ -272,7 +488,8 @@ __device__ __forceinline__ uint32_t cost_class(uint32_t c) {     // quarter-octa
 // by the product -- the host must hear of the frame's end before these kernels, not after (rt_api.hip: rt_enqueue).
 __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __restrict__ cost, uint32_t* __restrict__ scan, uint32_t* __restrict__ order,
                                                           uint32_t n, uint32_t wave_slots, uint32_t mult16, uint32_t cap16, uint32_t mult4,
-                                                          unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host, uint32_t words) {
+                                                          unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host, uint32_t words,
+                                                          uint32_t multw, unsigned long long* __restrict__ split_out) {
     static_assert(kOrderBlock == 256u, "rt_frame_epilogue_body is written for 256 threads");
     __shared__ uint32_t bin[128], start[128];
     __shared__ unsigned long long total;
@@ -308,7 +525,7 @@ __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __rest
         const unsigned long long thr = total / (2ull * (wave_slots ? wave_slots : 1u));
         auto cls_of = [&](unsigned long long v) { return cost_class(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v); };
         const uint32_t kt = cls_of((unsigned long long)mult4 * thr);           // mult4 / 2 times the throughput time: as quarters
-        const uint32_t kw = cls_of(4ull * thr);           // twice the throughput time
+        const uint32_t kw = cls_of((unsigned long long)multw * thr);           // multw / 2 times the throughput time (4: twice)
         const uint32_t k16 = cls_of((unsigned long long)mult16 * thr);          // mult16 / 2 times the throughput time: as sixteenths
         uint32_t split = start[kt], split16 = start[k16];      // tiles of the classes above the threshold's: all longer than it
         // some tile takes more than twice the throughput time: the frame waits for it.  (Otherwise quarters only add waves: 4K,
@@ -320,6 +537,9 @@ __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __rest
         if (split < split16) split = split16;
         order[0] = split - split16;                // tiles rendered as four quarters ...
         order[1] = split16;                        // ... behind the tiles rendered as sixteen 2x2 blocks: the head of the list
+        // ... and, for the host that launches the stream's next frame: does the list split anything?  (pinned memory; read without
+        // waiting for it: a frame late is as good)
+        if (split_out) __hip_atomic_store(split_out, (unsigned long long)split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (threadIdx.x < 128u) { scan[132u + threadIdx.x] = start[threadIdx.x]; scan[threadIdx.x] = 0u; }   // first positions; bins zero for the next frame
     if (threadIdx.x < 4u) scan[128u + threadIdx.x] = 0u;                                                // total, ticket
@@ -417,13 +637,30 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, 
     if (const char* e = getenv("RT355_TRI_XCD")) t.xcd_rows = t.xcd_rows && atoi(e) != 0;
 #endif
     const uint32_t padded = grid.x * ((grid.y + 7u) & ~7u);
+    // (a part of trace_roles takes about 0.6 of the time the same part takes in trace_triangles: its scaled time must say the same
+    // about the whole tile -- 1.5 / 0.6, 3 / 0.6, in eighths; profiles/r05/tri_roles.log)
+    t.cost_mul4 = 24u; t.cost_mul16 = 48u;
 #ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_ROLES")) t.roles = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT355_TRI_CM4")) t.cost_mul4 = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT355_TRI_CM16")) t.cost_mul16 = (uint32_t)atoi(e);
     if (const char* e = getenv("RT355_TRI_PRIO")) t.prio = (uint32_t)atoi(e);
     const size_t lds_pad = getenv("RT355_TRI_LDSPAD") ? (size_t)atoi(getenv("RT355_TRI_LDSPAD")) : 0u;
 #else
     const size_t lds_pad = 0u;
 #endif
     const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) + 15u * std::min(n_tiles / 64u, 256u) : (t.xcd_rows ? padded : n_tiles), 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
+    if constexpr (WAVES == 1 && PAIRS && P16 && (SMALL == 1 || SMALL == 3)) {
+        // an awaited frame with a work list: the form whose split tiles' idle lanes trace ahead (trace_roles)
+        if (t.tile_order && !heatmap && t.roles) {
+            g_rt_kernel_id = RT_KID_TRIANGLES_ROLES;
+            // (82 registers: twenty workgroups per CU where the LDS would hold twenty-one; held to 80 -- __launch_bounds__(64, 6) -- the
+            // kernel is 3 % slower, profiles/r05/tri_roles.log)
+            if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_roles<STK, OCC, true, SMALL>), line, dim3(64), lds_pad, s, a, t);
+            else            hipLaunchKernelGGL((rtk::trace_roles<STK, OCC, false, SMALL>), line, dim3(64), lds_pad, s, a, t);
+            return;
+        }
+    }
     if (heatmap) hipLaunchKernelGGL((rtk::heatmap_triangles<WAVES, STK, PACKED>), grid, dim3(64 * WAVES), 0, s, a, t);
     else if (a.sky_flat) hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, true, PACKED, PAIRS, P16, SMALL>), line, dim3(64 * WAVES), lds_pad, s, a, t);
     else                 hipLaunchKernelGGL((rtk::trace_triangles<WAVES, STK, OCC, false, PACKED, PAIRS, P16, SMALL>), line, dim3(64 * WAVES), lds_pad, s, a, t);
@@ -434,22 +671,23 @@ uint32_t rt_order_scan_words(void) { return 264u; }
 // order_hist (with the frame's epilogue in its first workgroup when `counters` is given: the caller records the frame's end event
 // behind it) and order_scatter, as two calls
 hipError_t rt_launch_order_hist(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, uint32_t wave_slots,
-                                unsigned long long* counters, unsigned long long* host, uint32_t words, hipStream_t s) {
+                                unsigned long long* counters, unsigned long long* host, uint32_t words, unsigned long long* split_out, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
     // Sixteenths from twice the throughput time on, at most 64 tiles (1 / 2 / 4 / 8 times: REF 0.459 / 0.449 / 0.537 / 0.539 ms one at a
     // time, TRI 0.255 / 0.256 / 0.291 / 0.372; 64 against 256 tiles: REF 0.449 against 0.465; a third level of single pixels
     // changes nothing: profiles/r04/tri_split_sweep16.log, tri_split_sweep64.log; again on round 5's kernel: profiles/r05/tri_split_sweep5.log).
     // launch_tri sizes the grid for 256.
-    uint32_t mult16 = 4u, cap16 = 64u, mult4 = 1u;
+    uint32_t mult16 = 4u, cap16 = 64u, mult4 = 1u, multw = 4u;
 #ifdef RT_TRI_DEV_ENV
     if (const char* e = getenv("RT355_TRI_MULT4")) mult4 = (uint32_t)atoi(e);
     if (const char* e = getenv("RT355_TRI_MULT16")) mult16 = (uint32_t)atoi(e);
     if (const char* e = getenv("RT355_TRI_CAP16")) cap16 = std::min(256u, (uint32_t)atoi(e));
     if (const char* e = getenv("RT355_TRI_SLOTS")) wave_slots = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT355_TRI_MULTW")) multw = (uint32_t)atoi(e);
 #endif
     const uint32_t per = rtk::kOrderBlock * rtk::kOrderPerThread, blocks = (n_tiles + per - 1u) / per;
     hipLaunchKernelGGL(rtk::order_hist, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles, wave_slots, mult16, cap16, mult4,
-                       counters, host, words);
+                       counters, host, words, multw, split_out);
     return hipGetLastError();
 }
 hipError_t rt_launch_order_scatter(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, hipStream_t s) {

@@ -64,7 +64,8 @@ typedef enum rt_kernel_id {
     RT_KID_HIERARCHY_16 = 6,     /* 16-wave workgroups, one per CU */
     RT_KID_HIERARCHY_GLOBAL = 7, /* nodes read from global memory (scenes beyond a CU's LDS) */
     RT_KID_TRIANGLES = 8,        /* trace_triangles (TLAS / BLAS traversal) */
-    RT_KID_HEATMAP = 9           /* heatmap_triangles */
+    RT_KID_HEATMAP = 9,          /* heatmap_triangles */
+    RT_KID_TRIANGLES_ROLES = 10  /* trace_roles: an awaited frame whose work list splits tiles -- the idle lanes of a part walk the next reflection ray while its pixels' lanes walk the shadow ray */
     /* (10, 11: the persistent triangle kernels of ABI 3 -- measured slower on every configuration, removed in ABI 4;
        docs/experiments.md keeps the account) */
 } rt_kernel_id;

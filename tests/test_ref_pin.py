@@ -142,3 +142,26 @@ def test_reference_scene_on_the_gpu_bit_exact(ref, oracle):
             assert r.stats()["rays"] == rays
     finally:
         r.close()
+
+
+@pytest.mark.gpu
+def test_reference_scene_awaited_frames_run_the_roles_kernel():
+    """The reference's loop awaits every frame (RR:467).  From the third awaited frame on a stream the work list made from the
+    previous one splits the scene's longest tiles, the pinned word order_hist leaves says so, and the frame runs as trace_roles
+    (a part's idle lanes walk the next reflection ray while its pixels' lanes walk the shadow ray): every frame the oracle's,
+    bit for bit, and the oracle's ray count -- no ray more, none less."""
+    from compute_raytracer_amd import abi
+    from helpers import ref_fixture
+    scene, sky, W, H, B, canvas, pin = ref_fixture()          # a fresh one: the test above has moved the shared scene
+    r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, rt.Material.white())
+    try:
+        kinds = []
+        for _ in range(24):                      # (an awaited frame's list is made from the previous frame on its stream)
+            r.render()
+            st = r.stats()
+            kinds.append(abi.KERNEL_IDS[st["kernel_id"]])
+            assert st["rays"] == pin["oracle_rays"], kinds
+            assert hashlib.sha256(r.read_pixels().tobytes()).hexdigest() == pin["oracle_frame_sha256_white_texture"], kinds
+        assert kinds[0] == "triangles" and "triangles_roles" in kinds[8:], kinds
+    finally:
+        r.close()

@@ -65,8 +65,8 @@ def short(name):
     return re.sub(r"\(.*", "", re.sub(r"^void\s+", "", name)).replace("rtk::", "")
 
 
-RAY_TRACE = re.compile(r"bvh_pixels|trace_pixels|trace_paths|first_bounce|trace_triangles|heatmap_triangles")
-GATHER = re.compile(r"trace_triangles|heatmap_triangles|sky_resolve")      # reads are gathers: FETCH_SIZE x 1 (see above;
+RAY_TRACE = re.compile(r"bvh_pixels|trace_pixels|trace_paths|first_bounce|trace_triangles|trace_roles|heatmap_triangles")
+GATHER = re.compile(r"trace_triangles|trace_roles|heatmap_triangles|sky_resolve")      # reads are gathers: FETCH_SIZE x 1 (see above;
 # sky_resolve reads 16 bytes per lane at a 32-byte stride plus texel gathers: its raw FETCH_SIZE, 1.044 GB per C5 frame, is the size of its records, 1.062 GB)
 
 

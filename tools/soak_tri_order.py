@@ -20,6 +20,7 @@ sky = rt.CubemapMaterial.constant(CONSTANT_SKY_RGBA)
 r = rt.RendererRaytracing(W, H, scene, maxBounces=B).initialize(sky, mat)
 rng = np.random.default_rng(7)
 bad, t0, f = [], time.time(), 0
+kinds = {}
 while f < frames:
     if (f // 40) % 3 == 2:                       # a batch in flight: four frames, each read back, then waited
         k = min(4, frames - f)
@@ -39,13 +40,15 @@ while f < frames:
     scene.camera.move(float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.05, 0.05)))
     if f % 50 == 49:                             # now and then the picture jumps: the list was made for another one
         scene.camera.move(float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)))
-    ref = orc.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)[0]
+    ref, _, rays = orc.render_tri(scene.pack_params(B), tri_buffers(scene, mat), sky.faces, W, H)
     r.render()
-    if not np.array_equal(r.read_pixels().reshape(H, W, 4), ref.reshape(H, W, 4)):
+    st = r.stats()
+    kinds[rt.abi.KERNEL_IDS[st["kernel_id"]]] = kinds.get(rt.abi.KERNEL_IDS[st["kernel_id"]], 0) + 1
+    if not np.array_equal(r.read_pixels().reshape(H, W, 4), ref.reshape(H, W, 4)) or st["rays"] != rays:
         bad.append(f)
     f += 1
     if f % 40 == 0:
         print("... %d frames, %d mismatching, %.0f s" % (f, len(bad), time.time() - t0), flush=True)
-print("soak_tri_order: %d frames %dx%d (%d tiles), %.1f s, mismatching frames %d %s" % (frames, W, H, ((W + 7) // 8) * ((H + 7) // 8), time.time() - t0, len(bad), bad[:8]))
+print("soak_tri_order: %d frames %dx%d (%d tiles), %.1f s, mismatching frames %d %s; awaited frames by kernel %s" % (frames, W, H, ((W + 7) // 8) * ((H + 7) // 8), time.time() - t0, len(bad), bad[:8], kinds))
 r.close()
 sys.exit(1 if bad else 0)
