@@ -986,7 +986,7 @@ int rt_enqueue(rt_ctx* c, uint8_t* dst, hipStream_t s) {
     if (tri) {
 #ifdef RT355_DEV_EXPORTS
         if (getenv("RT355_TRI_TIMELINE")) {
-            const size_t words = 3u * ((size_t)order_n + 3u * 1024u + 15u * 256u + 64u + 8u * ((c->W + 7u) / 8u));
+            const size_t words = 3u * ((size_t)order_n + 3u * 8192u + 15u * 256u + 64u + 8u * ((c->W + 7u) / 8u));
             if (c->d_tri_dbg.cap < words * 8u) { (void)hipFree(c->d_tri_dbg.p); c->d_tri_dbg.p = nullptr; RT_HIP(hipMalloc(&c->d_tri_dbg.p, words * 8u)); c->d_tri_dbg.cap = words * 8u; }
             RT_HIP(hipMemsetAsync(c->d_tri_dbg.p, 0, c->d_tri_dbg.cap, s));
             ts.dbg = static_cast<unsigned long long*>(c->d_tri_dbg.p);

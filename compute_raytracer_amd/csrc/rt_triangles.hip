@@ -489,7 +489,7 @@ __device__ __forceinline__ uint32_t cost_class(uint32_t c) {     // quarter-octa
 __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __restrict__ cost, uint32_t* __restrict__ scan, uint32_t* __restrict__ order,
                                                           uint32_t n, uint32_t wave_slots, uint32_t mult16, uint32_t cap16, uint32_t mult4,
                                                           unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host, uint32_t words,
-                                                          uint32_t multw, unsigned long long* __restrict__ split_out) {
+                                                          uint32_t multw, unsigned long long* __restrict__ split_out, uint32_t cap4, uint32_t div4) {
     static_assert(kOrderBlock == 256u, "rt_frame_epilogue_body is written for 256 threads");
     __shared__ uint32_t bin[128], start[128];
     __shared__ unsigned long long total;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(kOrderBlock) void order_hist(const uint32_t* __rest
         // some tile takes more than twice the throughput time: the frame waits for it.  (Otherwise quarters only add waves: 4K,
         // 0.77 -> 0.81 ms with them.)
         if (start[kw] == 0u) split = split16 = 0u;
-        const uint32_t most = n / 16u < 1024u ? n / 16u : 1024u, most16 = n / 64u < cap16 ? n / 64u : cap16;      // rt_tri_grid
+        const uint32_t most = n / div4 < cap4 ? n / div4 : cap4, most16 = n / 64u < cap16 ? n / 64u : cap16;      // (launch_tri sizes the grid for these)
         if (split16 > most16) split16 = most16;
         if (split > most) split = most;
         if (split < split16) split = split16;
@@ -627,6 +627,21 @@ hipError_t rt_launch_tri_corners(float4* out, const float* tri, const float* loo
 // WAVES: one wave per workgroup -- a workgroup's LDS and wave slots come free as soon as its own tile is done
 // (1 / 2 / 4 / 8 waves: 0.545 / 0.571 / 0.603 / 0.624 ms for the 1344x846 frame one at a time, 0.769 / 0.765 /
 // 0.792 / 0.883 ms per 4K frame in flight; profiles/r02/tri_waves.log).
+// the most tiles a work list renders in parts: one in kOrderDiv4, at most kOrderCap4 (order_hist caps its selection there, launch_tri
+// sizes the grid for it)
+static constexpr uint32_t kOrderCap4 = 1024u, kOrderDiv4 = 16u;
+static uint32_t order_cap4() {
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_CAP4")) return std::min(8192u, (uint32_t)atoi(e));
+#endif
+    return kOrderCap4;
+}
+static uint32_t order_div4() {
+#ifdef RT_TRI_DEV_ENV
+    if (const char* e = getenv("RT355_TRI_DIV4")) return std::max(2u, (uint32_t)atoi(e));
+#endif
+    return kOrderDiv4;
+}
 template <typename STK, int OCC, bool PACKED, int WAVES = 1, bool PAIRS = false, bool P16 = false, int SMALL = 0>
 static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, hipStream_t s) {
     const dim3 grid((a.W + 8u * WAVES - 1u) / (8u * WAVES), a.n_local_tiles, 1);
@@ -637,9 +652,11 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, 
     if (const char* e = getenv("RT355_TRI_XCD")) t.xcd_rows = t.xcd_rows && atoi(e) != 0;
 #endif
     const uint32_t padded = grid.x * ((grid.y + 7u) & ~7u);
-    // (a part of trace_roles takes about 0.6 of the time the same part takes in trace_triangles: its scaled time must say the same
-    // about the whole tile -- 1.5 / 0.6, 3 / 0.6, in eighths; profiles/r05/tri_roles.log)
-    t.cost_mul4 = 24u; t.cost_mul16 = 48u;
+    // (a part of trace_roles takes 0.6-0.7 of the time the same part takes in trace_triangles, and its scaled time must say the same
+    // about the whole tile: x 2 a quarter, x 4 a sixteenth, in eighths.  Swept on the reference's scene, nothing moving / its mesh
+    // turning: 12 / 24: 0.403 / 0.456 ms per awaited frame, 16 / 32: 0.356 / 0.455, 20 / 40: 0.356 / 0.464, 24 / 48: 0.361 / 0.476,
+    // 32 / 64: 0.362 / 0.500; profiles/r05/tri_roles_loop.log)
+    t.cost_mul4 = 16u; t.cost_mul16 = 32u;
 #ifdef RT_TRI_DEV_ENV
     if (const char* e = getenv("RT355_TRI_ROLES")) t.roles = (uint32_t)atoi(e);
     if (const char* e = getenv("RT355_TRI_CM4")) t.cost_mul4 = (uint32_t)atoi(e);
@@ -649,7 +666,7 @@ static void launch_tri(const RtFrameArgs& a, const RtTriScene& t0, int heatmap, 
 #else
     const size_t lds_pad = 0u;
 #endif
-    const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / 16u, 1024u) + 15u * std::min(n_tiles / 64u, 256u) : (t.xcd_rows ? padded : n_tiles), 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
+    const dim3 line(t.tile_order ? n_tiles + 3u * std::min(n_tiles / order_div4(), order_cap4()) + 15u * std::min(n_tiles / 64u, 256u) : (t.xcd_rows ? padded : n_tiles), 1, 1);   // order_tiles: at most that many tiles in quarters / sixteenths
     if constexpr (WAVES == 1 && PAIRS && P16 && (SMALL == 1 || SMALL == 3)) {
         // an awaited frame with a work list: the form whose split tiles' idle lanes trace ahead (trace_roles)
         if (t.tile_order && !heatmap && t.roles) {
@@ -687,7 +704,7 @@ hipError_t rt_launch_order_hist(uint32_t* cost, uint32_t* scan, uint32_t* order,
 #endif
     const uint32_t per = rtk::kOrderBlock * rtk::kOrderPerThread, blocks = (n_tiles + per - 1u) / per;
     hipLaunchKernelGGL(rtk::order_hist, dim3(blocks), dim3(rtk::kOrderBlock), 0, s, cost, scan, order, n_tiles, wave_slots, mult16, cap16, mult4,
-                       counters, host, words, multw, split_out);
+                       counters, host, words, multw, split_out, order_cap4(), order_div4());
     return hipGetLastError();
 }
 hipError_t rt_launch_order_scatter(uint32_t* cost, uint32_t* scan, uint32_t* order, uint32_t n_tiles, hipStream_t s) {
