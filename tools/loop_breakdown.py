@@ -40,4 +40,14 @@ for st in states:
     t_rec += t1 - t0; t_ren += t2 - t1; t_wait += t3 - t2; k.append(r.stats()["kernel_ms"])
 n = len(states)
 print("%-34s recalculateScene %.3f  rt_render %.3f  rt_wait %.3f  (kernel %.3f)  sum %.3f ms   prep_ms %.3f" % ("new instance data every step", t_rec / n * 1e3, t_ren / n * 1e3, t_wait / n * 1e3, sorted(k)[n // 2], (t_rec + t_ren + t_wait) / n * 1e3, r.stats().get("prep_ms", 0.0)))
+# is the turning mesh's extra kernel time the picture's (other poses cost more) or the list's (made from the previous pose)?  Every
+# pose rendered twice in a row: the second render has the list of its own picture
+k1, k2, kid = [], [], {}
+for st in states[::3]:
+    scene.frame = st
+    r.recalculateScene(); abi.check(L.rt_render(c), c); abi.check(L.rt_wait(c), c); k1.append(r.stats()["kernel_ms"])
+    abi.check(L.rt_render(c), c); abi.check(L.rt_wait(c), c); k2.append(r.stats()["kernel_ms"])
+    kid[r.stats()["kernel_id"]] = kid.get(r.stats()["kernel_id"], 0) + 1
+print("every third pose rendered twice: kernel median %.3f ms with the previous pose's list, %.3f with its own (kernel ids %s)"
+      % (sorted(k1)[len(k1) // 2], sorted(k2)[len(k2) // 2], kid))
 r.close()
