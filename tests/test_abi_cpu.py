@@ -30,6 +30,18 @@ def test_library_exports_every_declared_symbol():
     assert len(lib.rt_build_id()) == 16 and lib.rt_kernel_name(4) == b"bvh_pixels<8>"
 
 
+def test_kernel_ids_of_the_header_the_python_table_and_the_library_agree():
+    """rt_stats.kernel_id says which kernel rendered a frame: the enum of include/rt355.h, abi.KERNEL_IDS and rt_kernel_name must
+    list the same ids (10 = trace_roles, the awaited triangle frame whose work list splits tiles)."""
+    text = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    ids = {name: int(v) for name, v in re.findall(r"\b(RT_KID_[A-Z_0-9]+)\s*=\s*(\d+)", text)}
+    assert sorted(ids.values()) == sorted(abi.KERNEL_IDS) == list(range(len(ids)))
+    assert ids["RT_KID_TRIANGLES"] == 8 and ids["RT_KID_TRIANGLES_ROLES"] == 10 and abi.KERNEL_IDS[10] == "triangles_roles"
+    lib = abi.load()
+    names = [lib.rt_kernel_name(i) for i in sorted(ids.values())]
+    assert all(names) and len(set(names)) == len(names) and names[10] == b"trace_roles"
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():
