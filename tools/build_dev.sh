@@ -11,6 +11,9 @@ make -s lib
 /opt/rocm/bin/hipcc $FL -fno-slp-vectorize -DRT_BVH_DEV_ENV -c $CS/rt_bvh.hip -o /tmp/rtdev/rt_bvh.o &
 /opt/rocm/bin/hipcc $FL -fno-slp-vectorize -DRT_TRI_DEV_ENV -c $CS/rt_triangles.hip -o /tmp/rtdev/rt_triangles.o &
 wait
+# tools/dev_dilate.hip (an experiment on the work list's costs) stands in front of the library's rt_launch_order_hist: that one is renamed
+/opt/rocm/bin/hipcc $FL -c tools/dev_dilate.hip -o /tmp/rtdev/dev_dilate.o
+/opt/rocm/lib/llvm/bin/llvm-objcopy --redefine-sym _Z20rt_launch_order_histPjS_S_jjPyS0_jS0_P12ihipStream_t=_Z25rt_launch_order_hist_origPjS_S_jjPyS0_jS0_P12ihipStream_t /tmp/rtdev/rt_triangles.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/bin/librt355_dev.so /tmp/rtdev/rt_api.o /tmp/rtdev/rt_bvh.o \
-    $CS/rt_kernels.o /tmp/rtdev/rt_triangles.o $CS/rt_assemble.o $CS/rt_comm.o -L/opt/rocm/lib -lrccl
+    $CS/rt_kernels.o /tmp/rtdev/rt_triangles.o /tmp/rtdev/dev_dilate.o $CS/rt_assemble.o $CS/rt_comm.o -L/opt/rocm/lib -lrccl
 ls -la tools/bin/*.so
