@@ -271,6 +271,15 @@ def reduce_over_ranks(torch, dist, elapsed, rays_local, kernel_ms, gather_ms, se
             [float(v) for v in tmax[5 + n:]] if serial_regions else serial_regions)
 
 
+def agree_on_exchange(dist, world, error):
+    """Every rank brings its rt_comm_init verdict (None, or the library's message); all of them leave with the same answer:
+    ("rccl", None), or ("host", the first rank's message) if ANY rank was refused.  tests/test_tiles_gloo.py runs it over gloo."""
+    errs = [None] * world
+    dist.all_gather_object(errs, error)
+    first = next((e for e in errs if e), None)
+    return ("host", first) if first else ("rccl", None)
+
+
 def kernel_label(kernel_id):
     """What the library says it launched (rt_stats.kernel_id -- no copy of its dispatch rules here)."""
     from compute_raytracer_amd import abi
@@ -405,10 +414,8 @@ def main():
             r.comm_init(ids[0], rank, world)          # collective: ncclCommInitRank on this rank's GPU
         except rt.abi.RtError as e:
             exchange_error = "rank %d: %s" % (rank, e)
-        errs = [None] * world
-        dist.all_gather_object(errs, exchange_error)
-        if any(errs):
-            exchange, exchange_error = "host", next(e for e in errs if e)
+        exchange, exchange_error = agree_on_exchange(dist, world, exchange_error)
+        if exchange == "host":
             r.close()
             r = rt.RendererRaytracing(W, H, scene, device=local_rank, maxBounces=B, rank=rank, world=world)   # the partition without the communicator
             r.initialize(sky, mat)

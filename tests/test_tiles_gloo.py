@@ -158,3 +158,39 @@ def test_bench_reduction_over_ranks(tmp_path, world):
     mp.spawn(_reduce_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / ("rank%d" % r)).read() == "ok"
+
+
+def _exchange_worker(rank, world, port, W, H, result_dir):
+    import importlib.util
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        # nobody refused: the product's path; the LAST rank refused: every rank answers "host" with that rank's message
+        a = bench.agree_on_exchange(dist, world, None)
+        b = bench.agree_on_exchange(dist, world, "rank %d: refused" % rank if rank == world - 1 else None)
+        ok = a == ("rccl", None) and b == ("host", "rank %d: refused" % (world - 1))
+        # the labelled fallback's data path, as bench.py's step() does it: this rank's rows (tiles rank, rank + world, ...: only the
+        # frame's last tile can be short) into the zero-padded message, all-gather over gloo, de-interleave
+        frame = np.random.default_rng(5).integers(0, 256, (H, W, 4), dtype=np.uint8)       # the same picture on every rank
+        mine = np.concatenate([frame[8 * t:8 * t + 8] for t in range(rank, tiles.total_tiles(H), world)] or [np.zeros((0, W, 4), np.uint8)])
+        host_rows = np.zeros((tiles.padded_tiles(H, world) * 8, W, 4), dtype=np.uint8)
+        host_rows[:mine.shape[0]] = mine
+        g = tiles.all_gather_frame(torch.from_numpy(host_rows), W, H)
+        ok = ok and np.array_equal(tiles.assemble_torch(g, W, H, world).numpy(), frame)
+        open(os.path.join(result_dir, "rank%d" % rank), "w").write("ok" if ok else "MISMATCH %r %r" % (a, b))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H", [(2, 1080), (3, 1077), (2, 20)])
+def test_bench_exchange_verdict_and_host_fallback(tmp_path, world, H):
+    """bench.py with N > 1: the ranks agree on how the rows travel (one refused rt_comm_init sends ALL of them to the labelled host
+    exchange), and that exchange's buffer layout -- ragged tile counts, a short last tile -- rebuilds the frame."""
+    port = _free_port()
+    mp.spawn(_exchange_worker, args=(world, port, 64, H, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / ("rank%d" % r)).read() == "ok"
